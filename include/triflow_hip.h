@@ -1,0 +1,127 @@
+/* libtriflow_hip -- C ABI of the MI355X-native triflow hot path.
+ *
+ * Drop-in boundary.  Plain pointers and sizes only; all
+ * device memory is owned by the library, host pointers are borrowed for the
+ * duration of a call.  Every function returns 0 on success, non-zero on error
+ * (text via tf_last_error()); the Python host side raises RuntimeError from it,
+ * which is what the reference's Simulation turns into status = 'failed'
+ * (triflow/core/simulation.py:259-261).
+ *
+ * Reference interfaces replaced (paths relative to the reference tree):
+ *   seam #1  compiler plugin  compiler(model) -> (F_function, J_function)
+ *            triflow/core/model.py:299-311, callables invoked as
+ *            _ufunc(x, *dep_vars, *help_funcs, *pars, periodic)
+ *            triflow/core/routines.py:37-45, 82-91
+ *            -> tf_model_create, tf_solver_create, tf_set_*, tf_eval, tf_get_F, tf_get_J
+ *   seam #2  scheme plugin    scheme(t, fields, dt, pars, hook) -> (t, fields)
+ *            triflow/core/schemes.py:101-174 (ROW_general), 523-559 (Theta)
+ *            -> tf_step_theta, tf_step_row, tf_step_bdf2 (BDF-2 is new)
+ *   seam #3  linear-solver injection  Theta(model, solver=callable(A, b) -> x)
+ *            triflow/core/schemes.py:518-521, 557
+ *            -> tf_factor, tf_solve
+ *
+ * Threading: calls on one solver are not thread-safe; different solvers are
+ * independent (one HIP stream each).
+ */
+#ifndef TRIFLOW_HIP_H
+#define TRIFLOW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tf_model tf_model;
+typedef struct tf_solver tf_solver;
+
+/* Constants of one compiled model (produced by triflow_amd.codegen). */
+typedef struct tf_model_spec {
+    int32_t nvar;         /* dependent variables                                   */
+    int32_t nh;           /* help functions                                        */
+    int32_t npar;         /* physical parameters (without 'periodic')              */
+    int32_t mp;           /* ghost width: stencil window is 2*mp+1 nodes           */
+    int32_t nnz;          /* structurally non-null Jacobian entries per node       */
+    int32_t seg;          /* nodes per thread of the stencil sweep                 */
+    int32_t sweep_block;  /* workgroup size of the stencil sweep                   */
+    int32_t uses_x;       /* the expressions read the coordinate x                 */
+    uint32_t parvec_mask; /* bit k set: parameter k is a per-node array            */
+} tf_model_spec;
+
+typedef struct tf_solver_opts {
+    int32_t m1;           /* chunk length of the first solver level (0 = default)   */
+    int32_t m_upper;      /* chunk length of the reduced levels     (0 = default)   */
+    int32_t nstate;       /* resident state slots                   (0 = default 3) */
+    int32_t refine;       /* iterative-refinement sweeps per linear solve           */
+    int32_t device;       /* HIP device ordinal (-1 = current)                      */
+} tf_solver_opts;
+
+const char* tf_last_error(void);
+int tf_runtime_info(int32_t* is_device_build, int32_t* device_count);
+
+/* code object = gfx950 .hsaco image built from the generated per-model source */
+int tf_model_create(const tf_model_spec* spec, const void* code_object, size_t code_size,
+                    tf_model** out);
+void tf_model_destroy(tf_model* model);
+
+/* nsys independent systems (ensemble members) of N nodes each share one solver */
+int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
+                     const tf_solver_opts* opts, tf_solver** out);
+void tf_solver_destroy(tf_solver* solver);
+int tf_solver_describe(tf_solver* solver, int32_t* nlevels, int32_t* chunks /*[nlevels]*/,
+                       int32_t max_levels, int64_t* device_bytes);
+
+/* ---- inputs.  Arrays are [nsys][N] in natural node order. ------------------- */
+int tf_set_state(tf_solver*, int32_t slot, int32_t first_var, int32_t nvars, const double* host);
+int tf_get_state(tf_solver*, int32_t slot, int32_t first_var, int32_t nvars, double* host);
+int tf_set_state_flat(tf_solver*, int32_t slot, const double* uflat /*[nsys][N*nvar]*/);
+int tf_get_state_flat(tf_solver*, int32_t slot, double* uflat);
+int tf_copy_state(tf_solver*, int32_t src_slot, int32_t dst_slot);
+int tf_set_helpers(tf_solver*, int32_t first, int32_t count, const double* host);
+int tf_set_param_scalar(tf_solver*, int32_t k, const double* values /*[nsys]*/);
+int tf_set_param_vector(tf_solver*, int32_t k, const double* host /*[nsys][N]*/);
+int tf_set_dx(tf_solver*, const double* dx /*[nsys]*/);
+int tf_set_x(tf_solver*, const double* x /*[nsys][N]*/);
+/* declarative Dirichlet hook: U[var][node] = value (node < 0 counts from the end),
+ * applied where the reference schemes call hook() */
+int tf_set_dirichlet(tf_solver*, int32_t n, const int32_t* var, const int64_t* node,
+                     const double* value);
+
+/* ---- seam #1: F / J evaluation on the resident state ----------------------- */
+int tf_eval(tf_solver*, int32_t slot, int32_t with_j);
+int tf_get_F(tf_solver*, double* F /*[nsys][N*nvar], F[node*nvar+eq]*/);
+int tf_get_J(tf_solver*, double* Jvals /*[nsys][N][nnz], reference pattern order*/);
+
+/* ---- seam #3: (I - c J) x = b with the Jacobian of the last tf_eval -------- */
+int tf_factor(tf_solver*, double c);
+int tf_solve(tf_solver*, const double* rhs_flat /*[nsys][N*nvar]*/, double* x_flat);
+int tf_matvec(tf_solver*, const double* v_flat, double* y_flat);     /* y = J @ v */
+
+/* ---- seam #2: one time step, state slot src -> slot dst --------------------- */
+int tf_step_theta(tf_solver*, int32_t src, int32_t dst, double dt, double theta);
+/* alpha, gamma: [s][s] row major; b, b_pred: [s] (b_pred may be NULL);
+ * err_out (may be NULL) receives ||U - U_pred||_inf per system [nsys];
+ * hook_after: apply the Dirichlet list to the result (fixed-step __call__) */
+int tf_step_row(tf_solver*, int32_t src, int32_t dst, double dt, int32_t s,
+                const double* alpha, const double* gamma, const double* b,
+                const double* b_pred, int32_t hook_after, double* err_out);
+int tf_step_bdf2(tf_solver*, int32_t src, int32_t dst, double dt);
+int tf_bdf2_reset(tf_solver*);
+/* ||state[a] - state[b]||_ord per dependent variable and system, [nsys][nvar]
+ * (error estimate of the step-doubling wrapper, schemes.py:41-44); ord 2 or inf(0) */
+int tf_diff_norm(tf_solver*, int32_t slot_a, int32_t slot_b, int32_t ord, double* out);
+
+int tf_sync(tf_solver*);            /* waits for the stream, reports device-side failures */
+
+/* ---- measurement: HIP-event timing of every launch, per kernel ------------- */
+int tf_timing_enable(tf_solver*, int32_t on);
+int tf_timing_reset(tf_solver*);
+int tf_timing_get(tf_solver*, int32_t kernel, double* total_ms, int64_t* launches);
+int tf_kernel_count(void);
+const char* tf_kernel_name(int32_t kernel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

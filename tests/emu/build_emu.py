@@ -1,0 +1,66 @@
+"""TEST-ONLY: build the host emulation of the per-model kernels.
+
+Compiles triflow_amd/csrc/tf_runtime.cpp + tests/emu/tf_backend_emu.cpp +
+the generated model header with g++ into tests/emu/_build/emu_<hash>.so.  The
+resulting library exposes the same C ABI as libtriflow_hip.so but executes the
+kernel bodies on the CPU; it exists so that the CPU test suite can check the
+host orchestration and the kernel arithmetic against the oracle.  The
+triflow_amd package never loads it.
+"""
+import os
+import subprocess
+
+from triflow_amd import codegen
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "triflow_amd", "csrc")
+BUILD = os.path.join(HERE, "_build")
+
+
+def _deps_stamp():
+    parts = []
+    for d, names in ((CSRC, ("tf_args.h", "tf_math.h", "tf_kernels.h", "tf_runtime.cpp",
+                             "tf_backend.h")),
+                     (HERE, ("tf_backend_emu.cpp",)),
+                     (os.path.join(ROOT, "include"), ("triflow_hip.h",))):
+        for n in names:
+            with open(os.path.join(d, n), "rb") as f:
+                parts.append(f.read())
+    return codegen.source_hash(*parts)
+
+
+def build(model, parvec_mask=0, opt="-O1"):
+    """Returns (path of the emulation library, spec dict)."""
+    src, spec = codegen.lower_model(model, parvec_mask=parvec_mask)
+    tag = codegen.source_hash(src, _deps_stamp(), opt)
+    os.makedirs(BUILD, exist_ok=True)
+    so = os.path.join(BUILD, "emu_%s.so" % tag)
+    if not os.path.exists(so):
+        hdr = os.path.join(BUILD, "model_%s.h" % tag)
+        with open(hdr, "w") as f:
+            f.write(src)
+        cmd = ["g++", "-std=c++17", opt, "-g0", "-shared", "-fPIC", "-ffp-contract=off",
+               "-fno-fast-math", "-I", CSRC, "-I", os.path.join(ROOT, "include"),
+               '-DTF_EMU_MODEL_HEADER="%s"' % hdr,
+               os.path.join(CSRC, "tf_runtime.cpp"), os.path.join(HERE, "tf_backend_emu.cpp"),
+               "-o", so + ".tmp"]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("emulation build failed:\n" + res.stderr[-4000:])
+        os.replace(so + ".tmp", so)
+    return so, spec
+
+
+class EmuBackend:
+    """Drop-in for triflow_amd.compilers.HipBackend in CPU tests."""
+
+    def __init__(self):
+        self._libs = {}
+
+    def load(self, model, parvec_mask):
+        from triflow_amd._capi import DeviceModel, Library
+        so, spec = build(model, parvec_mask)
+        if so not in self._libs:
+            self._libs[so] = Library(so)
+        return DeviceModel(self._libs[so], spec, b"")

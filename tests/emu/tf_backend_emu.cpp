@@ -1,0 +1,96 @@
+// TEST-ONLY emulation of tf_backend.h: executes the kernel bodies of
+// triflow_amd/csrc/tf_kernels.h thread by thread on the host, so that the host
+// runtime (level planning, launch order, scheme drivers) and the kernel
+// arithmetic can be checked against the oracle in the CPU test suite.  Built
+// per model by tests/emu/build_emu.py into tests/emu/_build/; never linked into
+// libtriflow_hip.so and never imported by the triflow_amd package.
+#include "tf_backend.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+
+#define TF_DEVICE static inline
+#define TF_DEVICE_M inline
+#include "tf_math.h"
+using std::sqrt; using std::exp; using std::log; using std::sin; using std::cos; using std::tan;
+using std::tanh; using std::sinh; using std::cosh; using std::pow; using std::atan; using std::asin;
+using std::acos; using std::log10; using std::log2; using std::cbrt; using std::expm1; using std::log1p;
+using std::floor; using std::ceil;
+#include TF_EMU_MODEL_HEADER
+#include "tf_kernels.h"
+
+namespace tfb {
+
+struct Module { int dummy; };
+struct Stream { int dummy; };
+struct Event { int dummy; };
+
+bool is_device_build() { return false; }
+int device_count() { return 0; }
+void set_device(int) {}
+void* dev_alloc(size_t bytes) { void* p = std::calloc(bytes ? bytes : 8, 1); if (!p) throw std::bad_alloc(); return p; }
+void dev_free(void* p) { std::free(p); }
+void memset0(void* p, size_t bytes, Stream*) { std::memset(p, 0, bytes); }
+void h2d(void* d, const void* s, size_t n, Stream*) { std::memcpy(d, s, n); }
+void d2h(void* d, const void* s, size_t n, Stream*) { std::memcpy(d, s, n); }
+void d2d(void* d, const void* s, size_t n, Stream*) { std::memmove(d, s, n); }
+Module* module_load(const void*, size_t) { return new Module(); }
+void module_unload(Module* m) { delete m; }
+Stream* stream_create() { return new Stream(); }
+void stream_destroy(Stream* s) { delete s; }
+void stream_sync(Stream*) {}
+Event* event_create() { return new Event(); }
+void event_destroy(Event* e) { delete e; }
+void event_record(Event*, Stream*) {}
+float event_elapsed_ms(Event*, Event*) { return 0.f; }
+
+typedef TfRowsBT<TF_B2> TfRowsUp;
+
+void launch(Module*, int kernel, unsigned gx, unsigned gy, unsigned block,
+            const void* args, size_t, Stream*) {
+    const int64_t nthreads = (int64_t)gx * block;
+    switch (kernel) {
+    case TFK_SWEEP_F: { const auto& a = *(const TfSweepArgs*)args;
+        for (unsigned y = 0; y < gy; ++y) for (int64_t t = 0; t < nthreads; ++t) tfk_sweep_body<false>(a, (int)t, (int)y); } break;
+    case TFK_SWEEP_FJ: { const auto& a = *(const TfSweepArgs*)args;
+        for (unsigned y = 0; y < gy; ++y) for (int64_t t = 0; t < nthreads; ++t) tfk_sweep_body<true>(a, (int)t, (int)y); } break;
+    case TFK_SPMV: { const auto& a = *(const TfSpmvArgs*)args;
+        for (unsigned y = 0; y < gy; ++y) for (int64_t t = 0; t < nthreads; ++t) tfk_spmv_body(a, (int)t, (int)y); } break;
+    case TFK_VEC: { const auto& a = *(const TfVecArgs*)args;
+        for (int64_t i = 0; i < a.n; ++i) tfk_vec_elem(a, i); } break;
+    case TFK_VEC_MAXABS: { const auto& a = *(const TfVecArgs*)args;
+        double m = *a.red;
+        for (int64_t i = 0; i < a.n; ++i) { double v = tf_vec_err(a, i); m = (v > m || v != v) ? v : m; }
+        *a.red = m; } break;
+    case TFK_PERM: { const auto& a = *(const TfPermArgs*)args;
+        for (int64_t t = 0; t < nthreads; ++t) tfk_perm_elem(a, t); } break;
+    case TFK_DIRICHLET: { const auto& a = *(const TfDirichletArgs*)args;
+        for (int64_t t = 0; t < nthreads; ++t) tfk_dirichlet_elem(a, (int)t); } break;
+#define TF_EMU_CHUNK(ID, ROWS, SP, SU, SY)                                              \
+    case ID: { const auto& a = *(const TfLevelArgs*)args;                               \
+        for (int64_t t = 0; t < nthreads; ++t) tfk_chunk_body<ROWS, +1, SP, SU, SY>(a, (int)t); \
+        for (int64_t t = 0; t < nthreads; ++t) tfk_chunk_body<ROWS, -1, SP, false, false>(a, (int)t); } break;
+    TF_EMU_CHUNK(TFK_L1_FACTOR, TfRowsL1, true, true, false)
+    TF_EMU_CHUNK(TFK_L1_SOLVE, TfRowsL1, false, false, true)
+    TF_EMU_CHUNK(TFK_BT_FACTOR, TfRowsUp, true, true, false)
+    TF_EMU_CHUNK(TFK_BT_SOLVE, TfRowsUp, false, false, true)
+#define TF_EMU_LEVEL(ID, CALL)                                                          \
+    case ID: { const auto& a = *(const TfLevelArgs*)args;                               \
+        for (int64_t t = 0; t < nthreads; ++t) CALL(a, (int)t); } break;
+    TF_EMU_LEVEL(TFK_L1_ASM_MAT, (tfk_asm_body<TfRowsL1, true>))
+    TF_EMU_LEVEL(TFK_L1_ASM_RHS, (tfk_asm_body<TfRowsL1, false>))
+    TF_EMU_LEVEL(TFK_L1_BACKSUB, (tfk_backsub_body<TfRowsL1>))
+    TF_EMU_LEVEL(TFK_BT_ASM_MAT, (tfk_asm_body<TfRowsUp, true>))
+    TF_EMU_LEVEL(TFK_BT_ASM_RHS, (tfk_asm_body<TfRowsUp, false>))
+    TF_EMU_LEVEL(TFK_BT_BACKSUB, (tfk_backsub_body<TfRowsUp>))
+    case TFK_TOP_FACTOR: { const auto& a = *(const TfTopArgs*)args;
+        for (int64_t t = 0; t < nthreads; ++t) tfk_top_body<TF_B2, true>(a, (int)t); } break;
+    case TFK_TOP_SOLVE: { const auto& a = *(const TfTopArgs*)args;
+        for (int64_t t = 0; t < nthreads; ++t) tfk_top_body<TF_B2, false>(a, (int)t); } break;
+    default: throw std::runtime_error("emu: unknown kernel");
+    }
+}
+
+}  // namespace tfb

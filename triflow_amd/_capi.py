@@ -1,0 +1,306 @@
+"""ctypes binding of ``libtriflow_hip.so`` (C ABI in ``include/triflow_hip.h``).
+
+Thin by design: numpy arrays in, numpy arrays out, every non-zero return code
+becomes a ``RuntimeError`` carrying ``tf_last_error()``.
+"""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+c_int64_p = C.POINTER(C.c_int64)
+
+
+class ModelSpec(C.Structure):
+    _fields_ = [("nvar", C.c_int32), ("nh", C.c_int32), ("npar", C.c_int32),
+                ("mp", C.c_int32), ("nnz", C.c_int32), ("seg", C.c_int32),
+                ("sweep_block", C.c_int32), ("uses_x", C.c_int32),
+                ("parvec_mask", C.c_uint32)]
+
+
+class SolverOpts(C.Structure):
+    _fields_ = [("m1", C.c_int32), ("m_upper", C.c_int32), ("nstate", C.c_int32),
+                ("refine", C.c_int32), ("device", C.c_int32)]
+
+
+#: name -> (restype, argtypes); every symbol declared in include/triflow_hip.h
+SIGNATURES = {
+    "tf_last_error": (C.c_char_p, []),
+    "tf_runtime_info": (C.c_int, [c_int32_p, c_int32_p]),
+    "tf_model_create": (C.c_int, [C.POINTER(ModelSpec), C.c_void_p, C.c_size_t,
+                                  C.POINTER(C.c_void_p)]),
+    "tf_model_destroy": (None, [C.c_void_p]),
+    "tf_solver_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                   C.POINTER(SolverOpts), C.POINTER(C.c_void_p)]),
+    "tf_solver_destroy": (None, [C.c_void_p]),
+    "tf_solver_describe": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p, C.c_int32, c_int64_p]),
+    "tf_set_state": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_double_p]),
+    "tf_get_state": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_double_p]),
+    "tf_set_state_flat": (C.c_int, [C.c_void_p, C.c_int32, c_double_p]),
+    "tf_get_state_flat": (C.c_int, [C.c_void_p, C.c_int32, c_double_p]),
+    "tf_copy_state": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "tf_set_helpers": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_double_p]),
+    "tf_set_param_scalar": (C.c_int, [C.c_void_p, C.c_int32, c_double_p]),
+    "tf_set_param_vector": (C.c_int, [C.c_void_p, C.c_int32, c_double_p]),
+    "tf_set_dx": (C.c_int, [C.c_void_p, c_double_p]),
+    "tf_set_x": (C.c_int, [C.c_void_p, c_double_p]),
+    "tf_set_dirichlet": (C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int64_p, c_double_p]),
+    "tf_eval": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "tf_get_F": (C.c_int, [C.c_void_p, c_double_p]),
+    "tf_get_J": (C.c_int, [C.c_void_p, c_double_p]),
+    "tf_factor": (C.c_int, [C.c_void_p, C.c_double]),
+    "tf_solve": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "tf_matvec": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "tf_step_theta": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double]),
+    "tf_step_row": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_int32,
+                              c_double_p, c_double_p, c_double_p, c_double_p, C.c_int32,
+                              c_double_p]),
+    "tf_step_bdf2": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double]),
+    "tf_bdf2_reset": (C.c_int, [C.c_void_p]),
+    "tf_diff_norm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_double_p]),
+    "tf_sync": (C.c_int, [C.c_void_p]),
+    "tf_timing_enable": (C.c_int, [C.c_void_p, C.c_int32]),
+    "tf_timing_reset": (C.c_int, [C.c_void_p]),
+    "tf_timing_get": (C.c_int, [C.c_void_p, C.c_int32, c_double_p, c_int64_p]),
+    "tf_kernel_count": (C.c_int, []),
+    "tf_kernel_name": (C.c_char_p, [C.c_int32]),
+}
+
+
+def _dptr(arr):
+    return arr.ctypes.data_as(c_double_p)
+
+
+def _f64(a, shape=None):
+    out = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and out.shape != tuple(shape):
+        raise ValueError("expected array of shape %r, got %r" % (tuple(shape), out.shape))
+    return out
+
+
+class Library:
+    """A loaded ``libtriflow_hip.so`` with typed entry points."""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "HIP runtime library %s is missing -- build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)" % path)
+        self.path = path
+        self.dll = C.CDLL(path)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(self.dll, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+
+    def call(self, name, *args):
+        rc = getattr(self.dll, name)(*args)
+        if rc != 0:
+            raise RuntimeError("%s: %s" % (name, self.dll.tf_last_error().decode()))
+
+    def runtime_info(self):
+        dev, cnt = C.c_int32(0), C.c_int32(0)
+        self.call("tf_runtime_info", C.byref(dev), C.byref(cnt))
+        return bool(dev.value), cnt.value
+
+    def kernel_names(self):
+        return [self.dll.tf_kernel_name(k).decode() for k in range(self.dll.tf_kernel_count())]
+
+
+class DeviceModel:
+    """``tf_model``: a loaded per-model code object."""
+
+    def __init__(self, lib, spec, code):
+        self.lib = lib
+        self.spec = dict(spec)
+        cs = ModelSpec(spec["nvar"], spec["nh"], spec["npar"], spec["mp"], spec["nnz"],
+                       spec["seg"], spec["sweep_block"], spec["uses_x"], spec["parvec_mask"])
+        self._code = C.create_string_buffer(code, len(code)) if code else None
+        handle = C.c_void_p()
+        lib.call("tf_model_create", C.byref(cs),
+                 C.cast(self._code, C.c_void_p) if self._code is not None else None,
+                 len(code) if code else 0, C.byref(handle))
+        self.handle = handle
+
+    def close(self):
+        if self.handle:
+            self.lib.dll.tf_model_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceSolver:
+    """``tf_solver``: resident state + kernels for ``nsys`` systems of ``N`` nodes."""
+
+    def __init__(self, model, N, nsys=1, periodic=False, m1=0, m_upper=0, nstate=0,
+                 refine=0, device=-1):
+        self.model = model
+        self.lib = model.lib
+        self.N, self.nsys, self.periodic = int(N), int(nsys), bool(periodic)
+        self.nvar, self.nh = model.spec["nvar"], model.spec["nh"]
+        self.npar, self.nnz = model.spec["npar"], model.spec["nnz"]
+        opts = SolverOpts(m1, m_upper, nstate, refine, device)
+        handle = C.c_void_p()
+        self.lib.call("tf_solver_create", model.handle, self.N, self.nsys,
+                      int(self.periodic), C.byref(opts), C.byref(handle))
+        self.handle = handle
+        self.nstate = nstate if nstate > 0 else 3
+
+    def close(self):
+        if self.handle:
+            self.lib.dll.tf_solver_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def describe(self):
+        nl, nbytes = C.c_int32(0), C.c_int64(0)
+        chunks = (C.c_int32 * 32)()
+        self.lib.call("tf_solver_describe", self.handle, C.byref(nl), chunks, 32, C.byref(nbytes))
+        return dict(levels=nl.value, chunks=list(chunks[:nl.value]), device_bytes=nbytes.value)
+
+    # ------------------------------------------------------------------ inputs
+    def set_state(self, slot, arrays, first=0):
+        """``arrays``: [nvars][nsys][N] (or [nvars][N] when nsys == 1)."""
+        a = _f64(arrays).reshape(-1, self.nsys, self.N)
+        self.lib.call("tf_set_state", self.handle, slot, first, a.shape[0], _dptr(a))
+
+    def get_state(self, slot, first=0, nvars=None):
+        nvars = self.nvar - first if nvars is None else nvars
+        out = np.empty((nvars, self.nsys, self.N))
+        self.lib.call("tf_get_state", self.handle, slot, first, nvars, _dptr(out))
+        return out
+
+    def set_state_flat(self, slot, uflat):
+        a = _f64(uflat).reshape(self.nsys, self.N * self.nvar)
+        self.lib.call("tf_set_state_flat", self.handle, slot, _dptr(a))
+
+    def get_state_flat(self, slot):
+        out = np.empty((self.nsys, self.N * self.nvar))
+        self.lib.call("tf_get_state_flat", self.handle, slot, _dptr(out))
+        return out
+
+    def copy_state(self, src, dst):
+        self.lib.call("tf_copy_state", self.handle, src, dst)
+
+    def set_helpers(self, arrays, first=0):
+        a = _f64(arrays).reshape(-1, self.nsys, self.N)
+        self.lib.call("tf_set_helpers", self.handle, first, a.shape[0], _dptr(a))
+
+    def set_param(self, k, value):
+        """Scalar per system, or [nsys][N] per-node values when the model was
+        compiled with parameter ``k`` as a vector."""
+        if (self.model.spec["parvec_mask"] >> k) & 1:
+            a = _f64(np.broadcast_to(np.asarray(value, dtype=float), (self.nsys, self.N)))
+            self.lib.call("tf_set_param_vector", self.handle, k, _dptr(a))
+        else:
+            a = _f64(np.broadcast_to(np.asarray(value, dtype=float), (self.nsys,)))
+            self.lib.call("tf_set_param_scalar", self.handle, k, _dptr(a))
+
+    def set_dx(self, dx):
+        a = _f64(np.broadcast_to(np.asarray(dx, dtype=float), (self.nsys,)))
+        self.lib.call("tf_set_dx", self.handle, _dptr(a))
+
+    def set_x(self, x):
+        a = _f64(np.broadcast_to(np.asarray(x, dtype=float), (self.nsys, self.N)))
+        self.lib.call("tf_set_x", self.handle, _dptr(a))
+
+    def set_dirichlet(self, entries):
+        """``entries``: iterable of (variable index, node index, value)."""
+        entries = list(entries)
+        n = len(entries)
+        var = np.array([e[0] for e in entries], dtype=np.int32)
+        node = np.array([e[1] for e in entries], dtype=np.int64)
+        val = np.array([e[2] for e in entries], dtype=np.float64)
+        self.lib.call("tf_set_dirichlet", self.handle, n,
+                      var.ctypes.data_as(c_int32_p), node.ctypes.data_as(c_int64_p), _dptr(val))
+
+    # ----------------------------------------------------------------- seam #1
+    def eval(self, slot=0, with_j=False):
+        self.lib.call("tf_eval", self.handle, slot, int(with_j))
+
+    def get_F(self):
+        out = np.empty((self.nsys, self.N * self.nvar))
+        self.lib.call("tf_get_F", self.handle, _dptr(out))
+        return out
+
+    def get_J(self):
+        out = np.empty((self.nsys, self.N, max(self.nnz, 1)))
+        self.lib.call("tf_get_J", self.handle, _dptr(out))
+        return out[:, :, :self.nnz]
+
+    # ----------------------------------------------------------------- seam #3
+    def factor(self, c):
+        self.lib.call("tf_factor", self.handle, float(c))
+
+    def solve(self, rhs_flat):
+        rhs = _f64(rhs_flat).reshape(self.nsys, self.N * self.nvar)
+        out = np.empty_like(rhs)
+        self.lib.call("tf_solve", self.handle, _dptr(rhs), _dptr(out))
+        return out
+
+    def matvec(self, v_flat):
+        v = _f64(v_flat).reshape(self.nsys, self.N * self.nvar)
+        out = np.empty_like(v)
+        self.lib.call("tf_matvec", self.handle, _dptr(v), _dptr(out))
+        return out
+
+    # ----------------------------------------------------------------- seam #2
+    def step_theta(self, src, dst, dt, theta=1.0):
+        self.lib.call("tf_step_theta", self.handle, src, dst, float(dt), float(theta))
+
+    def step_row(self, src, dst, dt, alpha, gamma, b, b_pred=None, hook_after=False,
+                 want_err=True):
+        alpha, gamma = _f64(alpha), _f64(gamma)
+        b = _f64(b)
+        s = b.size
+        bp = _f64(b_pred) if b_pred is not None else None
+        err = C.c_double(0.0)
+        self.lib.call("tf_step_row", self.handle, src, dst, float(dt), s, _dptr(alpha),
+                      _dptr(gamma), _dptr(b), _dptr(bp) if bp is not None else None,
+                      int(hook_after), C.byref(err) if want_err else None)
+        return err.value if (want_err and bp is not None) else None
+
+    def step_bdf2(self, src, dst, dt):
+        self.lib.call("tf_step_bdf2", self.handle, src, dst, float(dt))
+
+    def bdf2_reset(self):
+        self.lib.call("tf_bdf2_reset", self.handle)
+
+    def diff_maxnorm(self, slot_a, slot_b):
+        out = C.c_double(0.0)
+        self.lib.call("tf_diff_norm", self.handle, slot_a, slot_b, 0, C.byref(out))
+        return out.value
+
+    def sync(self):
+        self.lib.call("tf_sync", self.handle)
+
+    # ------------------------------------------------------------- measurement
+    def timing(self, on=True):
+        self.lib.call("tf_timing_enable", self.handle, int(on))
+
+    def timing_reset(self):
+        self.lib.call("tf_timing_reset", self.handle)
+
+    def timing_report(self):
+        """{kernel name: (total ms, launches)} for kernels launched since reset."""
+        out = {}
+        for k, name in enumerate(self.lib.kernel_names()):
+            ms, n = C.c_double(0.0), C.c_int64(0)
+            self.lib.call("tf_timing_get", self.handle, k, C.byref(ms), C.byref(n))
+            if n.value:
+                out[name] = (ms.value, n.value)
+        return out

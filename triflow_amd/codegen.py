@@ -1,0 +1,257 @@
+"""Lower the SymPy stencil IR of a Model to the per-node C bodies that the
+hand-written kernel skeleton (csrc/tf_kernels.h) is specialised with.
+
+The reference hands ``model.F_array`` / ``model._J_sparse_array`` to
+``sympy.lambdify`` and lets NumPy evaluate the printed expression
+(``triflow/core/compilers.py:207-219``).  To compute *the same floating-point
+values*, this lowering starts from the very string SymPy's NumPy printer
+produces for that call, parses it with ``ast`` and emits C with the identical
+operation tree (no re-association, no common-subexpression rewriting, no FMA
+contraction; the C compiler may only share bit-identical subtrees).  Name
+overrides follow the reference's module dictionary: ``Heaviside`` is
+identically one (``compilers.py:204-205``), ``Max``/``Min`` are
+``numpy.maximum``/``minimum`` chains.
+"""
+
+import ast
+import hashlib
+import inspect
+
+import numpy as np
+from sympy import lambdify
+
+_FUNCS_1 = {"sqrt": "sqrt", "exp": "exp", "log": "log", "sin": "sin", "cos": "cos",
+            "tan": "tan", "tanh": "tanh", "sinh": "sinh", "cosh": "cosh",
+            "arctan": "atan", "arcsin": "asin", "arccos": "acos",
+            "abs": "tf_abs", "absolute": "tf_abs", "fabs": "tf_abs", "sign": "tf_sign",
+            "log10": "log10", "log2": "log2", "cbrt": "cbrt", "expm1": "expm1",
+            "log1p": "log1p", "floor": "floor", "ceil": "ceil"}
+
+
+class UnsupportedExpression(NotImplementedError):
+    pass
+
+
+def _dbl(value):
+    """C literal with the exact binary value of a Python number."""
+    f = float(value)
+    if f != value and not isinstance(value, float):
+        raise UnsupportedExpression("integer constant %r is not a double" % (value,))
+    if f == int(f) and abs(f) < 2 ** 53:
+        return "%d.0" % int(f)
+    return f.hex()          # C99 / C++17 hexadecimal floating literal
+
+
+class _CEmitter(ast.NodeVisitor):
+    def __init__(self, names):
+        self.names = names          # python identifier -> C expression
+
+    def visit_Name(self, node):
+        if node.id in self.names:
+            return self.names[node.id]
+        if node.id == "pi":
+            return _dbl(np.pi)
+        if node.id == "E":
+            return _dbl(np.e)
+        raise UnsupportedExpression("unknown symbol %r in stencil expression" % node.id)
+
+    def visit_Constant(self, node):
+        if isinstance(node.value, bool) or not isinstance(node.value, (int, float)):
+            raise UnsupportedExpression("constant %r" % (node.value,))
+        return _dbl(node.value)
+
+    def visit_UnaryOp(self, node):
+        operand = self.visit(node.operand)
+        if isinstance(node.op, ast.USub):
+            return "(-%s)" % operand
+        if isinstance(node.op, ast.UAdd):
+            return operand
+        raise UnsupportedExpression(ast.dump(node))
+
+    def visit_BinOp(self, node):
+        if isinstance(node.op, ast.Pow):
+            return self._pow(node)
+        ops = {ast.Add: "+", ast.Sub: "-", ast.Mult: "*", ast.Div: "/"}
+        for klass, sym in ops.items():
+            if isinstance(node.op, klass):
+                return "(%s %s %s)" % (self.visit(node.left), sym, self.visit(node.right))
+        raise UnsupportedExpression(ast.dump(node))
+
+    def _pow(self, node):
+        base = self.visit(node.left)
+        expo = node.right
+        neg = False
+        if isinstance(expo, ast.UnaryOp) and isinstance(expo.op, ast.USub):
+            neg, expo = True, expo.operand
+        if isinstance(expo, ast.Constant) and isinstance(expo.value, (int, float)) \
+                and not isinstance(expo.value, bool):
+            val = -expo.value if neg else expo.value
+            if val == 2:
+                return "tf_sq(%s)" % base          # numpy.power fast path: square
+            if val == 0.5:
+                return "sqrt(%s)" % base           # numpy.power fast path: sqrt
+            if val == 1:
+                return base
+            if val == -1:
+                return "(1.0 / %s)" % base         # numpy.power fast path: reciprocal
+            if float(val) == int(val) and abs(val) <= 16:
+                return "tf_powi(%s, %d)" % (base, int(val))
+            return "pow(%s, %s)" % (base, _dbl(val))
+        return "pow(%s, %s)" % (base, self.visit(node.right))
+
+    def visit_Call(self, node):
+        name = node.func.attr if isinstance(node.func, ast.Attribute) else node.func.id
+        if name == "Heaviside":
+            return "1.0"                           # reference compilers.py:204-205
+        if name == "reduce":                       # reduce(maximum, [a, b, ...])
+            op = node.args[0]
+            opname = op.attr if isinstance(op, ast.Attribute) else op.id
+            fn = {"maximum": "tf_max", "minimum": "tf_min"}.get(opname)
+            if fn is None or not isinstance(node.args[1], (ast.List, ast.Tuple)):
+                raise UnsupportedExpression("reduce(%s, ...)" % opname)
+            items = [self.visit(e) for e in node.args[1].elts]
+            out = items[0]
+            for item in items[1:]:
+                out = "%s(%s, %s)" % (fn, out, item)
+            return out
+        if name in ("amax", "amin"):               # older SymPy: amax((a, b), axis=0)
+            fn = "tf_max" if name == "amax" else "tf_min"
+            items = [self.visit(e) for e in node.args[0].elts]
+            out = items[0]
+            for item in items[1:]:
+                out = "%s(%s, %s)" % (fn, out, item)
+            return out
+        if name in ("maximum", "minimum"):
+            fn = "tf_max" if name == "maximum" else "tf_min"
+            return "%s(%s, %s)" % (fn, self.visit(node.args[0]), self.visit(node.args[1]))
+        if name in _FUNCS_1 and len(node.args) == 1:
+            return "%s(%s)" % (_FUNCS_1[name], self.visit(node.args[0]))
+        raise UnsupportedExpression("function %r is not supported by the HIP compiler" % name)
+
+    def generic_visit(self, node):
+        raise UnsupportedExpression(ast.dump(node))
+
+
+def _printed_expressions(symbolic_args, exprs):
+    """The element expressions of the list SymPy's lambdify would evaluate."""
+    if not exprs:
+        return []
+    func = lambdify(symbolic_args, exprs, modules=[{"Heaviside": lambda *a: 1}, "numpy"],
+                    cse=False)
+    src = inspect.getsource(func)
+    tree = ast.parse(src)
+    fdef = tree.body[0]
+    ret = fdef.body[-1]
+    if len(fdef.body) != 1 or not isinstance(ret, ast.Return) \
+            or not isinstance(ret.value, (ast.List, ast.Tuple)):
+        raise UnsupportedExpression("unexpected lambdify output:\n" + src)
+    return list(ret.value.elts)
+
+
+def _c_ident(name):
+    return "v_" + "".join(ch if ch.isalnum() else "_" for ch in name)
+
+
+def lower_model(model, parvec_mask=0, seg=8, sweep_block=64):
+    """Returns ``(source, spec)``: the per-model translation unit (without the
+    skeleton includes' contents) and the dict of constants the runtime needs."""
+    nvar = model._nvar
+    fields = list(model._dep_vars) + list(model._help_funcs)
+    nh = len(model._help_funcs)
+    pars = list(model._pars)
+    lo, hi = model._bounds
+    mp = (model._window_range - 1) // 2
+    if -lo != hi or hi != mp:
+        raise UnsupportedExpression("asymmetric stencil window %r" % (model._bounds,))
+    if mp < 1:
+        mp = 1          # purely local models still get the width-3 skeleton
+    if nvar + nh > 16 or len(pars) > 16:
+        raise UnsupportedExpression("too many fields / parameters for the HIP skeleton")
+    sparse = [int(k) for k in model._sparse_indices[0]]
+    nnz = len(sparse)
+    real_mp = (model._window_range - 1) // 2
+    pat_eq = [k % nvar for k in sparse]
+    pat_var = [(k // nvar) % nvar for k in sparse]
+    pat_off = [(k // nvar) // nvar - real_mp for k in sparse]
+
+    # python identifier (as printed by SymPy) -> C identifier
+    names = {}
+    decls = []
+    for f, name in enumerate(fields):
+        for off in range(-mp, mp + 1):
+            key = name if off == 0 else "%s_%s%d" % (name, "m" if off < 0 else "p", abs(off))
+            names[key] = _c_ident(key)
+            decls.append("const double %s = w[%d][%d];" % (_c_ident(key), f, off + mp))
+    for k, name in enumerate(pars):
+        names[name] = _c_ident(name)
+        decls.append("const double %s = par[%d];" % (_c_ident(name), k))
+    names["dx"] = "dx"
+    names["x"] = "xc"
+
+    emit = _CEmitter(names)
+    f_nodes = _printed_expressions(model._symbolic_args, model.F_array.tolist())
+    j_nodes = _printed_expressions(model._symbolic_args, model._J_sparse_array.tolist())
+    f_c = [emit.visit(n) for n in f_nodes]
+    j_c = [emit.visit(n) for n in j_nodes]
+    uses_x = any("xc" in _tokens(s) for s in f_c + j_c)
+
+    def body(outname, exprs):
+        lines = ["    " + d for d in decls]
+        lines += ["    (void)dx; (void)xc; (void)par;"]
+        lines += ["    %s[%d] = %s;" % (outname, i, e) for i, e in enumerate(exprs)]
+        return "\n".join(lines)
+
+    def arr(name, values, ctype="int"):
+        vals = ", ".join(str(v) for v in values) if values else "0"
+        return "static constexpr %s %s[%d] = {%s};" % (ctype, name, max(len(values), 1), vals)
+
+    par_is_vec = [1 if (parvec_mask >> k) & 1 else 0 for k in range(len(pars))]
+    src = "\n".join([
+        "// generated by triflow_amd.codegen -- do not edit",
+        "// equations: " + " ; ".join(str(e) for e in model._diff_eqs),
+        "#define TF_NVAR %d" % nvar,
+        "#define TF_NH %d" % nh,
+        "#define TF_MP %d" % mp,
+        "#define TF_NNZ %d" % nnz,
+        "#define TF_NPAR %d" % len(pars),
+        "#define TF_SEG %d" % seg,
+        "#define TF_SWEEP_BLOCK %d" % sweep_block,
+        "#define TF_USES_X %d" % (1 if uses_x else 0),
+        arr("tf_pat_eq", pat_eq), arr("tf_pat_var", pat_var), arr("tf_pat_off", pat_off),
+        arr("tf_par_is_vec", par_is_vec, "bool"),
+        "TF_DEVICE void tf_eval_F(const double (&w)[TF_NVAR + TF_NH][2 * TF_MP + 1], "
+        "const double* par, double dx, double xc, double* F) {",
+        body("F", f_c),
+        "}",
+        "TF_DEVICE void tf_eval_J(const double (&w)[TF_NVAR + TF_NH][2 * TF_MP + 1], "
+        "const double* par, double dx, double xc, double* J) {",
+        body("J", j_c),
+        "}",
+        ""])
+    spec = dict(nvar=nvar, nh=nh, npar=len(pars), mp=mp, nnz=nnz, seg=seg,
+                sweep_block=sweep_block, uses_x=int(uses_x), parvec_mask=int(parvec_mask),
+                b2=mp * nvar, pat_eq=pat_eq, pat_var=pat_var, pat_off=pat_off,
+                fields=fields, pars=pars)
+    return src, spec
+
+
+def _tokens(text):
+    out, cur = set(), ""
+    for ch in text:
+        if ch.isalnum() or ch == "_":
+            cur += ch
+        else:
+            if cur:
+                out.add(cur)
+            cur = ""
+    if cur:
+        out.add(cur)
+    return out
+
+
+def source_hash(*parts):
+    h = hashlib.sha256()
+    for part in parts:
+        h.update(part if isinstance(part, bytes) else str(part).encode())
+        h.update(b"\0")
+    return h.hexdigest()[:20]

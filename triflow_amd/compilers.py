@@ -1,0 +1,297 @@
+"""The HIP "compiler" plugin (seam #1 of the reference).
+
+``hip_compiler(model) -> (F_function, J_function)`` plays the role of the
+reference's ``numpy_compiler`` / ``theano_compiler``
+(``triflow/core/compilers.py:11, 181``): it lowers the model's symbolic stencil
+to a gfx950 code object (generated per-node bodies inside the hand-written
+kernel skeleton of ``csrc/tf_kernels.h``, built with ``hipcc --genco`` and
+cached by source hash) and returns callables obeying the positional
+``_ufunc(x, *dep_vars, *help_funcs, *pars, periodic)`` protocol of
+``triflow/core/routines.py:37-45, 82-91``: ``F`` comes back as a flat float64
+array in node-major order, ``J`` as a ``scipy.sparse.csc_matrix`` with the
+reference's (row, col) pattern (``compilers.py:303-331``).
+
+The two callables are the *drop-in* path (every call moves its inputs and
+outputs over PCIe).  The schemes of this package do not use them: they drive
+the resident state of the same :class:`CompiledModel` through ``device.py``.
+
+There is no CPU implementation behind this module: without ``hipcc`` or the
+built ``libtriflow_hip.so`` it raises.
+"""
+
+import logging
+import os
+import shutil
+import subprocess
+import threading
+
+import numpy as np
+import scipy.sparse as sps
+
+from . import codegen
+from ._capi import DeviceModel, DeviceSolver, Library
+
+log = logging.getLogger(__name__)
+log.addHandler(logging.NullHandler())
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "lib", "libtriflow_hip.so")
+CACHE_DIR = os.path.join(PKG_DIR, "_cache")
+GPU_ARCH = "gfx950"
+HIPCC_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=" + GPU_ARCH]
+
+_SKELETON = ("tf_args.h", "tf_math.h", "tf_kernels.h", "tf_entry_hip.h")
+_TU_HEAD = ('#include <hip/hip_runtime.h>\n'
+            '#define TF_DEVICE __device__ __forceinline__\n'
+            '#include "tf_math.h"\n')
+_TU_TAIL = '#include "tf_kernels.h"\n#include "tf_entry_hip.h"\n'
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the HIP compiler plugin needs the ROCm toolchain")
+    return exe
+
+
+def _skeleton_stamp():
+    parts = []
+    for name in _SKELETON:
+        with open(os.path.join(CSRC, name), "rb") as f:
+            parts.append(f.read())
+    return codegen.source_hash(*parts)
+
+
+def build_runtime_library(force=False):
+    """Compile ``csrc/tf_runtime.cpp`` + ``tf_backend_hip.cpp`` into
+    ``lib/libtriflow_hip.so`` (host code only; links libamdhip64)."""
+    srcs = [os.path.join(CSRC, "tf_runtime.cpp"), os.path.join(CSRC, "tf_backend_hip.cpp")]
+    deps = srcs + [os.path.join(CSRC, n) for n in ("tf_args.h", "tf_backend.h")] + \
+        [os.path.join(os.path.dirname(PKG_DIR), "include", "triflow_hip.h")]
+    if not force and os.path.exists(LIB_PATH) and \
+            all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    cmd = [_hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "--offload-arch=" + GPU_ARCH,
+           "-I", CSRC, *srcs, "-o", LIB_PATH + ".tmp"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building libtriflow_hip.so failed:\n" + res.stderr[-4000:])
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+def build_code_object(model, parvec_mask=0, seg=None, sweep_block=None):
+    """Model -> (path of the cached gfx950 code object, spec dict)."""
+    seg = seg or int(os.environ.get("TRIFLOW_SWEEP_SEG", "8"))
+    sweep_block = sweep_block or int(os.environ.get("TRIFLOW_SWEEP_BLOCK", "64"))
+    body, spec = codegen.lower_model(model, parvec_mask=parvec_mask, seg=seg,
+                                     sweep_block=sweep_block)
+    source = _TU_HEAD + body + _TU_TAIL
+    tag = codegen.source_hash(source, _skeleton_stamp(), " ".join(HIPCC_FLAGS))
+    os.makedirs(CACHE_DIR, exist_ok=True)
+    hsaco = os.path.join(CACHE_DIR, "model_%s.hsaco" % tag)
+    if not os.path.exists(hsaco):
+        hip = os.path.join(CACHE_DIR, "model_%s.hip" % tag)
+        with open(hip, "w") as f:
+            f.write(source)
+        tmp = hsaco + ".%d.tmp" % os.getpid()
+        cmd = [_hipcc(), *HIPCC_FLAGS, "-I", CSRC, "--genco", "-o", tmp, hip]
+        log.info("hipcc: compiling stencil + solver kernels for %s", model._diff_eqs)
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("hipcc failed on the generated kernels (%s):\n%s"
+                               % (hip, res.stderr[-4000:]))
+        os.replace(tmp, hsaco)
+    return hsaco, spec
+
+
+class HipBackend:
+    """hipcc + libtriflow_hip.so (the product back end)."""
+
+    _lib = None
+    _lock = threading.Lock()
+
+    def library(self):
+        with HipBackend._lock:
+            if HipBackend._lib is None:
+                HipBackend._lib = Library(LIB_PATH)
+            return HipBackend._lib
+
+    def load(self, model, parvec_mask):
+        hsaco, spec = build_code_object(model, parvec_mask)
+        lib = self.library()
+        is_dev, ndev = lib.runtime_info()
+        if ndev < 1:
+            raise RuntimeError("no HIP device visible: the triflow_amd compute path needs "
+                               "an MI355X (gfx950); there is no CPU fallback")
+        with open(hsaco, "rb") as f:
+            code = f.read()
+        return DeviceModel(lib, spec, code)
+
+
+_default_backend = HipBackend()
+
+
+# --------------------------------------------------------------------------
+# Jacobian pattern (compilers.py:303-331), computed once per (N, periodic)
+# --------------------------------------------------------------------------
+class CscPattern:
+    """Fixed CSC structure of the Jacobian and the map from the raw
+    ``[N, nnz]`` value table to its ``data`` array (duplicates from clamped
+    ghost columns are summed in table order, like ``csc_matrix((data, (rows,
+    cols)))`` does)."""
+
+    def __init__(self, nvar, mp, sparse_indices, N, periodic):
+        k = np.asarray(sparse_indices, dtype=np.int64)
+        eq, slot = k % nvar, k // nvar
+        var, off = slot % nvar, slot // nvar - mp
+        node = np.arange(N, dtype=np.int64)[:, None]
+        neigh = node + off[None, :]
+        neigh = neigh % N if periodic else np.clip(neigh, 0, N - 1)
+        rows = (node * nvar + eq[None, :]).ravel()
+        cols = (neigh * nvar + var[None, :]).ravel()
+        n = N * nvar
+        key = cols * n + rows                       # CSC order: column major
+        uniq, inverse = np.unique(key, return_inverse=True)
+        self.shape = (n, n)
+        self.slot = inverse
+        self.nslots = uniq.size
+        self.indices = (uniq % n).astype(np.int32 if n < 2 ** 31 else np.int64)
+        ucols = uniq // n
+        self.indptr = np.searchsorted(ucols, np.arange(n + 1)).astype(self.indices.dtype)
+
+    def assemble(self, values):
+        data = np.bincount(self.slot, weights=np.asarray(values).ravel(),
+                           minlength=self.nslots)
+        return sps.csc_matrix((data, self.indices, self.indptr), shape=self.shape)
+
+
+# --------------------------------------------------------------------------
+class CompiledModel:
+    """Device side of one Model: code objects per parameter layout, resident
+    solvers per (N, periodic, nsys), and the host boundary of seam #1."""
+
+    def __init__(self, model, backend=None):
+        self.model = model
+        self.backend = backend or _default_backend
+        self.nvar = model._nvar
+        self.fields = list(model._dep_vars) + list(model._help_funcs)
+        self.nh = len(model._help_funcs)
+        self.pars = list(model._pars)
+        self.mp = max((model._window_range - 1) // 2, 1)
+        self.real_mp = (model._window_range - 1) // 2
+        self._device_models = {}
+        self._solvers = {}
+        self._patterns = {}
+        # fail at compile time, like the reference does, if the expressions
+        # cannot be lowered
+        codegen.lower_model(model)
+
+    # ---- code objects / solvers ------------------------------------------------
+    def device_model(self, parvec_mask=0):
+        if parvec_mask not in self._device_models:
+            self._device_models[parvec_mask] = self.backend.load(self.model, parvec_mask)
+        return self._device_models[parvec_mask]
+
+    def solver(self, N, periodic, nsys=1, parvec_mask=0, **opts):
+        key = (int(N), bool(periodic), int(nsys), int(parvec_mask), tuple(sorted(opts.items())))
+        if key not in self._solvers:
+            dm = self.device_model(parvec_mask)
+            self._solvers[key] = DeviceSolver(dm, N, nsys=nsys, periodic=periodic, **opts)
+        return self._solvers[key]
+
+    def pattern(self, N, periodic):
+        key = (int(N), bool(periodic))
+        if key not in self._patterns:
+            self._patterns[key] = CscPattern(self.nvar, self.real_mp,
+                                             self.model._sparse_indices[0], N, periodic)
+        return self._patterns[key]
+
+    def release(self):
+        for s in self._solvers.values():
+            s.close()
+        self._solvers.clear()
+
+    # ---- binding inputs ----------------------------------------------------------
+    @staticmethod
+    def grid_spacing(x):
+        """``dx = (x[-1] - x[0]) / (N - 1)``; a ``dx`` parameter is ignored
+        (reference compilers.py:234-237)."""
+        x = np.asarray(x)
+        return (x[-1] - x[0]) / (x.size - 1)
+
+    def parvec_mask_of(self, par_values):
+        mask = 0
+        for k, v in enumerate(par_values):
+            if np.ndim(v) > 0 and np.size(v) > 1 and np.ptp(v) != 0:
+                mask |= 1 << k
+        return mask
+
+    def bind_inputs(self, solver, x, par_values, helper_arrays=None):
+        solver.set_dx(self.grid_spacing(x))
+        solver.set_x(x)
+        mask = solver.model.spec["parvec_mask"]
+        for k, v in enumerate(par_values):
+            if (mask >> k) & 1:
+                solver.set_param(k, np.asarray(v, dtype=float))
+            else:
+                solver.set_param(k, float(np.ravel(v)[0]))
+        if self.nh and helper_arrays is not None:
+            solver.set_helpers(np.asarray(helper_arrays, dtype=float))
+
+    # ---- seam #1 callables ---------------------------------------------------------
+    def _unpack(self, args):
+        x = np.asarray(args[0], dtype=float)
+        nf = self.nvar + self.nh
+        fields = [np.asarray(a, dtype=float) for a in args[1:1 + nf]]
+        pars = list(args[1 + nf:1 + nf + len(self.pars)])
+        periodic = bool(args[1 + nf + len(self.pars)])
+        if len(args) != 2 + nf + len(self.pars):
+            raise TypeError("expected %d positional arguments, got %d"
+                            % (2 + nf + len(self.pars), len(args)))
+        return x, fields, pars, periodic
+
+    def _evaluate(self, args, with_j):
+        x, fields, pars, periodic = self._unpack(args)
+        mask = self.parvec_mask_of(pars)
+        solver = self.solver(x.size, periodic, 1, mask)
+        self.bind_inputs(solver, x, pars, fields[self.nvar:] if self.nh else None)
+        solver.set_state(0, np.asarray(fields[:self.nvar]))
+        solver.eval(0, with_j=with_j)
+        return solver, x.size, periodic
+
+    def F_function(self, *args):
+        solver, N, periodic = self._evaluate(args, with_j=False)
+        return solver.get_F()[0]
+
+    def J_function(self, *args):
+        solver, N, periodic = self._evaluate(args, with_j=True)
+        return self.pattern(N, periodic).assemble(solver.get_J()[0])
+
+
+def hip_compiler(model, backend=None):
+    """``compiler(model) -> (F_function, J_function)`` for the MI355X."""
+    compiled = CompiledModel(model, backend)
+
+    def F_function(*args):
+        return compiled.F_function(*args)
+
+    def J_function(*args):
+        return compiled.J_function(*args)
+
+    F_function.device_model = compiled
+    J_function.device_model = compiled
+    return F_function, J_function
+
+
+def resolve_compiler(name):
+    """String spellings accepted by ``Model(compiler=...)``.  The reference maps
+    ``"theano"`` / ``"numpy"`` to its two CPU back ends (model.py:152-155); this
+    framework has a single back end, so every spelling selects it."""
+    if name in ("hip", "theano", "numpy"):
+        if name != "hip":
+            log.info("compiler=%r requested: using the HIP compiler (only back end)", name)
+        return hip_compiler
+    raise ValueError("unknown compiler %r" % (name,))

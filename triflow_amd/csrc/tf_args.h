@@ -1,0 +1,130 @@
+// Plain-data launch argument blocks shared by the host runtime (tf_runtime.cpp)
+// and the per-model kernels (tf_kernels.h).  Every kernel takes exactly one of
+// these structs by value.
+#pragma once
+#include <stdint.h>
+
+#define TF_MAX_FIELDS 16   // dependent variables + help functions
+#define TF_MAX_PARS 16
+#define TF_MAX_TERMS 8
+
+// Partition-interleaved layout of one solver level.
+//
+// A system of N nodes is cut into P chunks of consecutive nodes; the first
+// `rem` chunks own mbase+1 nodes, the others mbase.  Node i of chunk p of
+// system e is stored at element  i * Ptot + (e * P + p)  of a plane, so that
+// the 64 lanes of a wavefront, which work on 64 neighbouring chunks, always
+// touch 512 contiguous bytes, whatever i is.  One thread then walks *along* a
+// chunk with its stencil neighbourhood in registers.
+struct TfLayout {
+    int nsys;      // independent systems (ensemble members)
+    int N;         // nodes per system
+    int P;         // chunks per system
+    int mbase;     // base chunk length
+    int rem;       // chunks [0, rem) are one node longer
+    int M;         // rows of a plane = mbase + (rem > 0)
+    int Ptot;      // nsys * P = row stride of a plane
+    int periodic;
+    int64_t plane; // M * Ptot elements
+};
+
+struct TfSweepArgs {               // F / F+J stencil sweep, J @ v, A-row build
+    TfLayout L;
+    const double* fields;          // [nvar] planes: dependent variables
+    const double* helpers;         // [nh] planes: help functions
+    const double* parvec;          // [npar] planes (only those flagged vector are read)
+    const double* parsca;          // [npar][nsys] scalar parameter values
+    const double* dx;              // [nsys]
+    const double* xcoord;          // 1 plane (only read when the model uses x)
+    double* F;                     // [nvar] planes
+    double* Jv;                    // [nnz] planes (raw values, reference pattern order)
+    int with_j;
+};
+
+struct TfSpmvArgs {                // y = scale * J @ v  (clamped/wrapped columns)
+    TfLayout L;
+    const double* Jv;
+    const double* v;               // [nvar] planes
+    double* y;                     // [nvar] planes
+    double scale;
+};
+
+struct TfVecArgs {                 // elementwise plane algebra
+    int64_t n;                     // elements (nvar * plane)
+    int nterms;
+    int op;
+    double* out;
+    const double* base;
+    const double* x[TF_MAX_TERMS];
+    double c[TF_MAX_TERMS];
+    double* red;                   // reduction target (max-norm)
+};
+
+struct TfPermArgs {                // natural order <-> partition-interleaved
+    TfLayout L;
+    const double* src;
+    double* dst;
+    int ncomp;                     // components handled (planes / interleave width)
+    int mode;
+};
+
+struct TfDirichletArgs {
+    TfLayout L;
+    double* fields;
+    int n;
+    const int* var;
+    const int* node;               // node index inside a system (applied to all systems)
+    const double* value;
+};
+
+// One level of the banded solver.  Level 1 reads its block rows from the
+// Jacobian planes (A = I - c J, built on the fly); levels >= 2 read the
+// explicit block-tridiagonal reduced system produced by the level below.
+struct TfLevelArgs {
+    TfLayout L;
+    // level 1 matrix source
+    const double* Jv;
+    double c;
+    // level >= 2 matrix source: [3][b][b] planes (sub, diag, super)
+    const double* Ablk;
+    // right-hand side in / solution out: [B] planes
+    const double* rhs;
+    double* x;
+    // factor storage (down direction): Ut [MP][B][B], Et [MP][B][B] planes; yt [B] planes
+    double* Ut;
+    double* Et;
+    double* yt;
+    // spike tips, SoA over chunks: see tf_kernels.h (TipLayout)
+    double* tips_dn;
+    double* tips_up;
+    // next (coarser) level: matrix / rhs written by the assemble kernels,
+    // solution read by the back-substitution
+    TfLayout Lnext;
+    double* Anext;
+    double* rhsnext;
+    const double* xnext;
+    int* status;                   // != 0 when a pivot block was singular / non-finite
+};
+
+struct TfTopArgs {                 // final 1-node system per ensemble member
+    int nsys;
+    const double* A;               // [3][b][b] planes with Ptot = nsys
+    const double* rhs;             // [b] planes
+    double* Ainv;                  // [b][b] planes
+    double* x;                     // [b] planes
+    int* status;
+};
+
+// Kernel table: index = launch id used by the runtime, name = entry point in
+// the per-model code object (tf_entry_hip.h).
+enum TfKernel {
+    TFK_SWEEP_F = 0, TFK_SWEEP_FJ, TFK_SPMV, TFK_VEC, TFK_VEC_MAXABS, TFK_PERM, TFK_DIRICHLET,
+    TFK_L1_FACTOR, TFK_L1_SOLVE, TFK_L1_ASM_MAT, TFK_L1_ASM_RHS, TFK_L1_BACKSUB,
+    TFK_BT_FACTOR, TFK_BT_SOLVE, TFK_BT_ASM_MAT, TFK_BT_ASM_RHS, TFK_BT_BACKSUB,
+    TFK_TOP_FACTOR, TFK_TOP_SOLVE, TFK_COUNT
+};
+#define TF_KERNEL_NAMES { \
+    "tfk_sweep_f", "tfk_sweep_fj", "tfk_spmv", "tfk_vec", "tfk_vec_maxabs", "tfk_perm", "tfk_dirichlet", \
+    "tfk_l1_factor", "tfk_l1_solve", "tfk_l1_asm_mat", "tfk_l1_asm_rhs", "tfk_l1_backsub", \
+    "tfk_bt_factor", "tfk_bt_solve", "tfk_bt_asm_mat", "tfk_bt_asm_rhs", "tfk_bt_backsub", \
+    "tfk_top_factor", "tfk_top_solve" }

@@ -1,0 +1,45 @@
+// Device back end used by tf_runtime.cpp: memory, stream, code-object loading,
+// kernel launch, event timing.  tf_backend_hip.cpp is the product
+// implementation (HIP on gfx950).  tests/emu/tf_backend_emu.cpp is a test-only
+// stand-in that executes the same kernel bodies thread by thread on the host so
+// that the host orchestration can be exercised without a GPU; it is never part
+// of libtriflow_hip.so.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <string>
+
+namespace tfb {
+
+struct Module;      // loaded code object + kernel handles
+struct Stream;
+struct Event;
+
+bool is_device_build();
+int device_count();
+void set_device(int ordinal);                 // throws std::runtime_error
+
+void* dev_alloc(size_t bytes);                // zero-initialised
+void dev_free(void* p);
+void memset0(void* p, size_t bytes, Stream* s);
+void h2d(void* dst, const void* src, size_t bytes, Stream* s);     // synchronous w.r.t. host
+void d2h(void* dst, const void* src, size_t bytes, Stream* s);     // synchronous w.r.t. host
+void d2d(void* dst, const void* src, size_t bytes, Stream* s);
+
+Module* module_load(const void* image, size_t bytes);
+void module_unload(Module* m);
+
+Stream* stream_create();
+void stream_destroy(Stream* s);
+void stream_sync(Stream* s);
+
+// one launch: grid (gx, gy, 1), block (block, 1, 1), one by-value argument struct
+void launch(Module* m, int kernel, unsigned gx, unsigned gy, unsigned block,
+            const void* args, size_t arg_bytes, Stream* s);
+
+Event* event_create();
+void event_destroy(Event* e);
+void event_record(Event* e, Stream* s);
+float event_elapsed_ms(Event* a, Event* b);   // both completed
+
+}  // namespace tfb

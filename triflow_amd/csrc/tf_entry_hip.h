@@ -1,0 +1,91 @@
+// __global__ entry points of a per-model code object (gfx950).  Included last
+// by the generated translation unit; names are fixed so that the host runtime
+// (tf_runtime.cpp, kernel table TF_KERNEL_NAMES) finds them with
+// hipModuleGetFunction.
+#pragma once
+
+#define TF_GID ((int)(blockIdx.x * blockDim.x + threadIdx.x))
+
+extern "C" {
+
+// ---- stencil sweeps: block (64,1,1), grid (chunks/64, segments) ------------
+__global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_sweep_f(TfSweepArgs a) {
+    tfk_sweep_body<false>(a, TF_GID, blockIdx.y);
+}
+__global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_sweep_fj(TfSweepArgs a) {
+    tfk_sweep_body<true>(a, TF_GID, blockIdx.y);
+}
+__global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_spmv(TfSpmvArgs a) {
+    tfk_spmv_body(a, TF_GID, blockIdx.y);
+}
+
+// ---- plane algebra: grid-stride, 16 B per lane where the planes allow ------
+__global__ void __launch_bounds__(256) tfk_vec(TfVecArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = TF_GID; i < a.n; i += stride) tfk_vec_elem(a, i);
+}
+
+// max |sum_t c_t x_t| : wavefront shuffle -> LDS -> one atomic per block.  The
+// bit pattern of a non-negative double is monotone in its value.
+__global__ void __launch_bounds__(256) tfk_vec_maxabs(TfVecArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double m = 0.0;
+    for (int64_t i = TF_GID; i < a.n; i += stride) {
+        const double v = tf_vec_err(a, i);
+        m = (v > m || v != v) ? v : m;            // NaN wins, like np.linalg.norm(inf)
+    }
+    unsigned long long bits = (unsigned long long)__double_as_longlong(m);
+    if (m != m) bits = 0x7ff8000000000000ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(bits, off, 64);
+        bits = o > bits ? o : bits;
+    }
+    __shared__ unsigned long long part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) part[wave] = bits;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) bits = part[w] > bits ? part[w] : bits;
+        atomicMax((unsigned long long*)a.red, bits);
+    }
+}
+
+__global__ void __launch_bounds__(256) tfk_perm(TfPermArgs a) {
+    tfk_perm_elem(a, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+__global__ void __launch_bounds__(64) tfk_dirichlet(TfDirichletArgs a) {
+    tfk_dirichlet_elem(a, TF_GID);
+}
+
+// ---- banded solver, level 1 (rows from the Jacobian planes) ----------------
+// grid.y: 0 = walk down, 1 = walk up (wave-uniform)
+__global__ void __launch_bounds__(64) tfk_l1_factor(TfLevelArgs a) {
+    if (blockIdx.y == 0) tfk_chunk_body<TfRowsL1, +1, true, true, false>(a, TF_GID);
+    else tfk_chunk_body<TfRowsL1, -1, true, false, false>(a, TF_GID);
+}
+__global__ void __launch_bounds__(64) tfk_l1_solve(TfLevelArgs a) {
+    if (blockIdx.y == 0) tfk_chunk_body<TfRowsL1, +1, false, false, true>(a, TF_GID);
+    else tfk_chunk_body<TfRowsL1, -1, false, false, false>(a, TF_GID);
+}
+__global__ void __launch_bounds__(64) tfk_l1_asm_mat(TfLevelArgs a) { tfk_asm_body<TfRowsL1, true>(a, TF_GID); }
+__global__ void __launch_bounds__(64) tfk_l1_asm_rhs(TfLevelArgs a) { tfk_asm_body<TfRowsL1, false>(a, TF_GID); }
+__global__ void __launch_bounds__(64) tfk_l1_backsub(TfLevelArgs a) { tfk_backsub_body<TfRowsL1>(a, TF_GID); }
+
+// ---- banded solver, levels >= 2 (explicit block-tridiagonal rows) -----------
+typedef TfRowsBT<TF_B2> TfRowsUp;
+__global__ void __launch_bounds__(64) tfk_bt_factor(TfLevelArgs a) {
+    if (blockIdx.y == 0) tfk_chunk_body<TfRowsUp, +1, true, true, false>(a, TF_GID);
+    else tfk_chunk_body<TfRowsUp, -1, true, false, false>(a, TF_GID);
+}
+__global__ void __launch_bounds__(64) tfk_bt_solve(TfLevelArgs a) {
+    if (blockIdx.y == 0) tfk_chunk_body<TfRowsUp, +1, false, false, true>(a, TF_GID);
+    else tfk_chunk_body<TfRowsUp, -1, false, false, false>(a, TF_GID);
+}
+__global__ void __launch_bounds__(64) tfk_bt_asm_mat(TfLevelArgs a) { tfk_asm_body<TfRowsUp, true>(a, TF_GID); }
+__global__ void __launch_bounds__(64) tfk_bt_asm_rhs(TfLevelArgs a) { tfk_asm_body<TfRowsUp, false>(a, TF_GID); }
+__global__ void __launch_bounds__(64) tfk_bt_backsub(TfLevelArgs a) { tfk_backsub_body<TfRowsUp>(a, TF_GID); }
+__global__ void __launch_bounds__(64) tfk_top_factor(TfTopArgs a) { tfk_top_body<TF_B2, true>(a, TF_GID); }
+__global__ void __launch_bounds__(64) tfk_top_solve(TfTopArgs a) { tfk_top_body<TF_B2, false>(a, TF_GID); }
+
+}  // extern "C"

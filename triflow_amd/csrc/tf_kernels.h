@@ -1,0 +1,888 @@
+// Hand-written CDNA4 kernel skeletons of the triflow hot path.
+//
+// This header is included by a small per-model translation unit that the HIP
+// compiler plugin (triflow_amd/compilers.py) generates at Model.compile time:
+// the unit defines the model constants (TF_NVAR, TF_MP, the Jacobian sparsity
+// pattern, ...) and the two per-node stencil bodies tf_eval_F / tf_eval_J that
+// were lowered from the SymPy expressions; everything else -- data layout,
+// neighbourhood handling, store pattern, the banded solver -- is fixed code
+// below.  It replaces (reference file:line)
+//   * compute_F_numpy / compute_J_numpy / init_computation_numpy
+//       triflow/core/compilers.py:227-332            -> tfk_sweep
+//   * CSC `J @ v`                 triflow/core/schemes.py:157,553 -> tfk_spmv
+//   * scipy.sparse.linalg.spsolve / factorized (SuperLU)
+//       triflow/core/schemes.py:149,557               -> tfk_chunk_* / tfk_asm_* / tfk_backsub / tfk_top_*
+//   * the NumPy vector algebra of the schemes
+//       triflow/core/schemes.py:152-174,553           -> tfk_vec
+//
+// Layout: see TfLayout in tf_args.h.  All loads and stores of the big arrays are
+// 8 bytes per lane, 512 contiguous bytes per wavefront instruction; a thread
+// walks along its chunk of consecutive nodes and keeps the (2*mp+1)-wide stencil
+// neighbourhood of every field in registers, so each field value is read from
+// HBM once per sweep and ghost cells only exist at chunk ends (served by the
+// neighbouring lane's column, i.e. the same cache lines).
+//
+// The same source compiles for the host (TF_DEVICE empty) in the test-only
+// emulation build under tests/emu/, which runs these very functions thread by
+// thread on the CPU; the product library never contains that build.
+#pragma once
+#include "tf_args.h"
+
+#ifndef TF_DEVICE
+#error "define TF_DEVICE (e.g. __device__ __forceinline__) before including tf_kernels.h"
+#endif
+
+#define TF_W (2 * TF_MP + 1)
+#define TF_NF (TF_NVAR + TF_NH)
+#define TF_B2 (TF_MP * TF_NVAR)          // block size of the reduced (interface) systems
+
+#include "tf_math.h"
+
+// ------------------------------------------------------------------- layout
+TF_DEVICE int tf_len(const TfLayout& L, int p) { return L.mbase + (p < L.rem ? 1 : 0); }
+TF_DEVICE int tf_start(const TfLayout& L, int p) { return p * L.mbase + (p < L.rem ? p : L.rem); }
+TF_DEVICE int64_t tf_idx(const TfLayout& L, int pg, int i) { return (int64_t)i * L.Ptot + pg; }
+
+// element of the node `d` places after node i of chunk (e, p); wraps or clamps
+// at the ends of the system exactly like the ghost cells of
+// triflow/core/compilers.py:257-264.  Needs |d| <= mbase.
+TF_DEVICE int64_t tf_nbr(const TfLayout& L, int e, int p, int len, int i, int d) {
+    int ii = i + d;
+    int pp = p;
+    if (ii < 0) {
+        if (p > 0) { pp = p - 1; ii += tf_len(L, pp); }
+        else if (L.periodic) { pp = L.P - 1; ii += tf_len(L, pp); }
+        else ii = 0;
+    } else if (ii >= len) {
+        if (p < L.P - 1) { pp = p + 1; ii -= len; }
+        else if (L.periodic) { pp = 0; ii -= len; }
+        else ii = len - 1;
+    }
+    return tf_idx(L, e * L.P + pp, ii);
+}
+
+// node index -> (chunk, row)
+TF_DEVICE void tf_locate(const TfLayout& L, int g, int& p, int& i) {
+    int big = L.rem * (L.mbase + 1);
+    if (g < big) { p = g / (L.mbase + 1); i = g - p * (L.mbase + 1); }
+    else { int h = g - big; p = L.rem + h / L.mbase; i = h - (h / L.mbase) * L.mbase; }
+}
+
+// ===========================================================================
+// 1. F / F+J stencil sweep                       (compilers.py:227-332)
+// ===========================================================================
+// grid: x over chunks (all systems), y over segments of TF_SEG nodes.
+template <bool WITH_J>
+TF_DEVICE void tfk_sweep_body(const TfSweepArgs& a, int pg, int seg) {
+    const TfLayout& L = a.L;
+    if (pg >= L.Ptot) return;
+    const int e = pg / L.P, p = pg - e * L.P;
+    const int len = tf_len(L, p);
+    const int i0 = seg * TF_SEG;
+    if (i0 >= len) return;
+
+    double par[TF_NPAR > 0 ? TF_NPAR : 1];
+#pragma unroll
+    for (int k = 0; k < TF_NPAR; ++k)
+        if (!tf_par_is_vec[k]) par[k] = a.parsca[k * L.nsys + e];
+    const double dx = a.dx[e];
+
+    auto ld = [&](int f, int ii) -> double {
+        const double* plane = f < TF_NVAR ? a.fields + (int64_t)f * L.plane
+                                          : a.helpers + (int64_t)(f - TF_NVAR) * L.plane;
+        if (ii >= 0 && ii < len) return plane[tf_idx(L, pg, ii)];
+        return plane[tf_nbr(L, e, p, len, 0, ii)];
+    };
+
+    double w[TF_NF][TF_W];
+#pragma unroll
+    for (int f = 0; f < TF_NF; ++f)
+#pragma unroll
+        for (int o = 1; o < TF_W; ++o) w[f][o] = ld(f, i0 - TF_MP + o - 1);
+
+#pragma unroll
+    for (int j = 0; j < TF_SEG; ++j) {
+        const int i = i0 + j;
+        if (i < len) {
+#pragma unroll
+            for (int f = 0; f < TF_NF; ++f) {
+#pragma unroll
+                for (int o = 0; o < TF_W - 1; ++o) w[f][o] = w[f][o + 1];
+                w[f][TF_W - 1] = ld(f, i + TF_MP);
+            }
+            const int64_t s = tf_idx(L, pg, i);
+#pragma unroll
+            for (int k = 0; k < TF_NPAR; ++k)
+                if (tf_par_is_vec[k]) par[k] = a.parvec[(int64_t)k * L.plane + s];
+            double xc = 0.0;
+            if (TF_USES_X) xc = a.xcoord[s];
+            double Fo[TF_NVAR];
+            tf_eval_F(w, par, dx, xc, Fo);
+#pragma unroll
+            for (int v = 0; v < TF_NVAR; ++v) a.F[(int64_t)v * L.plane + s] = Fo[v];
+            if (WITH_J) {
+                double Jo[TF_NNZ > 0 ? TF_NNZ : 1];
+                tf_eval_J(w, par, dx, xc, Jo);
+#pragma unroll
+                for (int k = 0; k < TF_NNZ; ++k) a.Jv[(int64_t)k * L.plane + s] = Jo[k];
+            }
+        }
+    }
+}
+
+// ===========================================================================
+// 2. y = scale * (J @ v)      (CSC product of schemes.py:157, 553; the column
+//    of a stored value is the clamped / wrapped neighbour, compilers.py:303-328)
+// ===========================================================================
+TF_DEVICE void tfk_spmv_body(const TfSpmvArgs& a, int pg, int seg) {
+    const TfLayout& L = a.L;
+    if (pg >= L.Ptot) return;
+    const int e = pg / L.P, p = pg - e * L.P;
+    const int len = tf_len(L, p);
+    const int i0 = seg * TF_SEG;
+    if (i0 >= len) return;
+    auto ld = [&](int v, int ii) -> double {
+        const double* plane = a.v + (int64_t)v * L.plane;
+        if (ii >= 0 && ii < len) return plane[tf_idx(L, pg, ii)];
+        return plane[tf_nbr(L, e, p, len, 0, ii)];
+    };
+    double w[TF_NVAR][TF_W];
+#pragma unroll
+    for (int v = 0; v < TF_NVAR; ++v)
+#pragma unroll
+        for (int o = 1; o < TF_W; ++o) w[v][o] = ld(v, i0 - TF_MP + o - 1);
+#pragma unroll
+    for (int j = 0; j < TF_SEG; ++j) {
+        const int i = i0 + j;
+        if (i < len) {
+#pragma unroll
+            for (int v = 0; v < TF_NVAR; ++v) {
+#pragma unroll
+                for (int o = 0; o < TF_W - 1; ++o) w[v][o] = w[v][o + 1];
+                w[v][TF_W - 1] = ld(v, i + TF_MP);
+            }
+            const int64_t s = tf_idx(L, pg, i);
+            double acc[TF_NVAR];
+#pragma unroll
+            for (int v = 0; v < TF_NVAR; ++v) acc[v] = 0.0;
+#pragma unroll
+            for (int k = 0; k < TF_NNZ; ++k) {       // pattern order = ascending column
+                const double jv = a.scale * a.Jv[(int64_t)k * L.plane + s];
+                acc[tf_pat_eq[k]] = acc[tf_pat_eq[k]] + jv * w[tf_pat_var[k]][tf_pat_off[k] + TF_MP];
+            }
+#pragma unroll
+            for (int v = 0; v < TF_NVAR; ++v) a.y[(int64_t)v * L.plane + s] = acc[v];
+        }
+    }
+}
+
+// ===========================================================================
+// 3. elementwise plane algebra of the schemes (schemes.py:152-174, 553)
+//    written without contraction, in the association order NumPy uses
+// ===========================================================================
+enum TfVecOp {
+    TF_VEC_SUM = 0,        // out = base + (((c0*x0) + c1*x1) + ...)       (base optional)
+    TF_VEC_LIN2 = 1,       // out = c0*x0 + c1*x1
+    TF_VEC_THETA_RHS = 2,  // out = c0*(x0 - x1) + x2       B = dt*(F - theta*J@U) + U
+    TF_VEC_MAXABS = 3,     // red = max |(((c0*x0) + c1*x1) + ...)|          (error estimate)
+    TF_VEC_COPY = 4,       // out = x0
+    TF_VEC_BDF2_RHS = 5,   // out = c0*(x0 - x1) + c1*x2    1/3 (U - Uprev) + 2/3 dt F
+    TF_VEC_ADD = 6,        // out = x0 + x1
+    TF_VEC_RESID = 7,      // out = (x0 - x1) + x2          r = b - x + c J x
+};
+
+TF_DEVICE double tf_vec_sum(const TfVecArgs& a, int64_t i) {
+    double acc = a.c[0] * a.x[0][i];
+    for (int t = 1; t < a.nterms; ++t) acc = acc + a.c[t] * a.x[t][i];
+    return acc;
+}
+// element of the ROW error estimate: |U - U_pred| with U_pred = U + sum_i b_pred_i k_i
+// formed from the updated U (schemes.py:167-174); plain |sum| without a base
+TF_DEVICE double tf_vec_err(const TfVecArgs& a, int64_t i) {
+    const double acc = tf_vec_sum(a, i);
+    return tf_abs(a.base ? a.base[i] - (a.base[i] + acc) : acc);
+}
+
+TF_DEVICE void tfk_vec_elem(const TfVecArgs& a, int64_t i) {
+    switch (a.op) {
+    case TF_VEC_SUM: {
+        double acc = tf_vec_sum(a, i);
+        a.out[i] = a.base ? a.base[i] + acc : acc;
+    } break;
+    case TF_VEC_LIN2: a.out[i] = a.c[0] * a.x[0][i] + a.c[1] * a.x[1][i]; break;
+    case TF_VEC_THETA_RHS: a.out[i] = a.c[0] * (a.x[0][i] - a.x[1][i]) + a.x[2][i]; break;
+    case TF_VEC_COPY: a.out[i] = a.x[0][i]; break;
+    case TF_VEC_BDF2_RHS: a.out[i] = a.c[0] * (a.x[0][i] - a.x[1][i]) + a.c[1] * a.x[2][i]; break;
+    case TF_VEC_ADD: a.out[i] = a.x[0][i] + a.x[1][i]; break;
+    case TF_VEC_RESID: a.out[i] = (a.x[0][i] - a.x[1][i]) + a.x[2][i]; break;
+    default: break;
+    }
+}
+
+// ===========================================================================
+// 4. natural order <-> partition-interleaved copies (host boundary only)
+// ===========================================================================
+enum TfPermMode {
+    TF_PERM_IN_SOA = 0,      // src [ncomp][nsys][N]          -> dst planes
+    TF_PERM_OUT_SOA = 1,     // src planes                    -> dst [ncomp][nsys][N]
+    TF_PERM_OUT_AOS = 2,     // src planes                    -> dst [nsys][N][ncomp]  (uflat / J value table)
+    TF_PERM_IN_AOS = 3,      // src [nsys][N][ncomp]          -> dst planes
+};
+
+TF_DEVICE void tfk_perm_elem(const TfPermArgs& a, int64_t t) {
+    const TfLayout& L = a.L;
+    const int64_t per = (int64_t)L.nsys * L.N;
+    if (t >= per) return;
+    const int e = (int)(t / L.N), g = (int)(t - (int64_t)e * L.N);
+    int p, i;
+    tf_locate(L, g, p, i);
+    const int64_t s = tf_idx(L, e * L.P + p, i);
+    for (int c = 0; c < a.ncomp; ++c) {
+        switch (a.mode) {
+        case TF_PERM_IN_SOA: a.dst[(int64_t)c * L.plane + s] = a.src[(int64_t)c * per + t]; break;
+        case TF_PERM_OUT_SOA: a.dst[(int64_t)c * per + t] = a.src[(int64_t)c * L.plane + s]; break;
+        case TF_PERM_OUT_AOS: a.dst[t * a.ncomp + c] = a.src[(int64_t)c * L.plane + s]; break;
+        case TF_PERM_IN_AOS: a.dst[(int64_t)c * L.plane + s] = a.src[t * a.ncomp + c]; break;
+        }
+    }
+}
+
+// declarative Dirichlet hook: U[var][node] = value in every system
+TF_DEVICE void tfk_dirichlet_elem(const TfDirichletArgs& a, int t) {
+    const TfLayout& L = a.L;
+    if (t >= a.n * L.nsys) return;
+    const int k = t % a.n, e = t / a.n;
+    int g = a.node[k];
+    if (g < 0) g += L.N;
+    int p, i;
+    tf_locate(L, g, p, i);
+    a.fields[(int64_t)a.var[k] * L.plane + tf_idx(L, e * L.P + p, i)] = a.value[k];
+}
+
+// ===========================================================================
+// 5. block-banded direct solver
+// ===========================================================================
+// A = I - c J is block banded: blocks of B = nvar unknowns per node, half
+// bandwidth MP nodes, cyclic when the system is periodic.  Every chunk of the
+// layout is split into its first len-MP nodes (interior) and its last MP nodes
+// (separator).  The interiors are mutually independent once the separators
+// are known, so
+//   factor:  two threads per chunk eliminate the interior by block LU (partial
+//            pivoting inside the B x B pivot block), one walking down, one
+//            walking up, each carrying the coupling to the separator behind it
+//            as extra right-hand sides ("spike").  Their last MP nodes give the
+//            response of the chunk ends to the separator values (tips).
+//   assemble: one thread per separator folds the tips of the chunks above and
+//            below into a block-tridiagonal system of MP*B x MP*B blocks over
+//            the separators -- the next level, solved the same way, until one
+//            chunk is left whose separator system is a single block.
+//   solve:   the same walk with one right-hand side (the elimination is
+//            recomputed from J: 8*nnz bytes/node instead of reading stored L
+//            factors), then back-substitution top level first, reading the
+//            stored normalised U rows.
+
+template <int B> struct TfBlk { double v[B][B]; };
+
+template <int B>
+TF_DEVICE void tf_blk_zero(double (&a)[B][B]) {
+#pragma unroll
+    for (int r = 0; r < B; ++r)
+#pragma unroll
+        for (int c = 0; c < B; ++c) a[r][c] = 0.0;
+}
+template <int B>
+TF_DEVICE void tf_blk_copy(double (&d)[B][B], const double (&s)[B][B]) {
+#pragma unroll
+    for (int r = 0; r < B; ++r)
+#pragma unroll
+        for (int c = 0; c < B; ++c) d[r][c] = s[r][c];
+}
+// C -= A * Bm
+template <int B>
+TF_DEVICE void tf_mm_sub(double (&C)[B][B], const double (&A)[B][B], const double (&Bm)[B][B]) {
+#pragma unroll
+    for (int r = 0; r < B; ++r)
+#pragma unroll
+        for (int c = 0; c < B; ++c) {
+            double acc = C[r][c];
+#pragma unroll
+            for (int k = 0; k < B; ++k) acc = tf_fma(-A[r][k], Bm[k][c], acc);
+            C[r][c] = acc;
+        }
+}
+// C = A * Bm
+template <int B>
+TF_DEVICE void tf_mm(double (&C)[B][B], const double (&A)[B][B], const double (&Bm)[B][B]) {
+#pragma unroll
+    for (int r = 0; r < B; ++r)
+#pragma unroll
+        for (int c = 0; c < B; ++c) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < B; ++k) acc = tf_fma(A[r][k], Bm[k][c], acc);
+            C[r][c] = acc;
+        }
+}
+template <int B>
+TF_DEVICE void tf_mv_sub(double (&y)[B], const double (&A)[B][B], const double (&x)[B]) {
+#pragma unroll
+    for (int r = 0; r < B; ++r) {
+        double acc = y[r];
+#pragma unroll
+        for (int k = 0; k < B; ++k) acc = tf_fma(-A[r][k], x[k], acc);
+        y[r] = acc;
+    }
+}
+template <int B>
+TF_DEVICE void tf_mv(double (&y)[B], const double (&A)[B][B], const double (&x)[B]) {
+#pragma unroll
+    for (int r = 0; r < B; ++r) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < B; ++k) acc = tf_fma(A[r][k], x[k], acc);
+        y[r] = acc;
+    }
+}
+
+// Gauss-Jordan inverse with partial (row) pivoting, all in registers.
+template <int B>
+TF_DEVICE bool tf_blk_inverse(const double (&A)[B][B], double (&inv)[B][B]) {
+    double a[B][B];
+    tf_blk_copy<B>(a, A);
+#pragma unroll
+    for (int r = 0; r < B; ++r)
+#pragma unroll
+        for (int c = 0; c < B; ++c) inv[r][c] = (r == c) ? 1.0 : 0.0;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+#pragma unroll
+        for (int r = k + 1; r < B; ++r) {          // bubble the largest |a[r][k]| up to row k
+            const bool sw = tf_abs(a[r][k]) > tf_abs(a[k][k]);
+#pragma unroll
+            for (int c = 0; c < B; ++c) {
+                const double t0 = a[k][c], t1 = a[r][c];
+                a[k][c] = sw ? t1 : t0;
+                a[r][c] = sw ? t0 : t1;
+                const double u0 = inv[k][c], u1 = inv[r][c];
+                inv[k][c] = sw ? u1 : u0;
+                inv[r][c] = sw ? u0 : u1;
+            }
+        }
+        const double piv = a[k][k];
+        ok = ok && (piv != 0.0) && tf_finite(piv);
+        const double rp = 1.0 / piv;
+#pragma unroll
+        for (int c = 0; c < B; ++c) { a[k][c] *= rp; inv[k][c] *= rp; }
+#pragma unroll
+        for (int r = 0; r < B; ++r) {
+            if (r == k) continue;
+            const double f = a[r][k];
+#pragma unroll
+            for (int c = 0; c < B; ++c) {
+                a[r][c] = tf_fma(-f, a[k][c], a[r][c]);
+                inv[r][c] = tf_fma(-f, inv[k][c], inv[r][c]);
+            }
+        }
+    }
+    return ok;
+}
+
+// ---- spike tips of one chunk, struct-of-arrays over chunks -----------------
+// y[k][B], V[k][t][B][B] (response to the separator ABOVE), W[k][t][B][B]
+// (response to the separator BELOW); k = tip node, t = separator node, both in
+// natural (top to bottom) order:  x_tip[k] = y[k] - sum_t V[k][t] s_above[t]
+//                                                 - sum_t W[k][t] s_below[t]
+template <int B, int MP> struct TfTips {
+    static constexpr int NY = MP * B;
+    static constexpr int NV = MP * MP * B * B;
+    static constexpr int SIZE = NY + 2 * NV;
+    TF_DEVICE_M static int y(int k, int r) { return k * B + r; }
+    TF_DEVICE_M static int V(int k, int t, int r, int c) { return NY + ((k * MP + t) * B + r) * B + c; }
+    TF_DEVICE_M static int W(int k, int t, int r, int c) { return NY + NV + ((k * MP + t) * B + r) * B + c; }
+};
+
+// ---- block-row providers ----------------------------------------------------
+// load(i, row): row[MP + d] = A(node i, node i + d), d = -MP..MP, in the natural
+// orientation, for a node i of the thread's own chunk.
+
+// level 1: A = I - c J from the raw Jacobian value planes.  For a clamped
+// system the ghost columns fold onto the boundary node (duplicates summed,
+// compilers.py:330-331).
+struct TfRowsL1 {
+    static constexpr int B = TF_NVAR;
+    static constexpr int MP = TF_MP;
+    const TfLevelArgs& a;
+    int pg, e, p, len, start;
+    TF_DEVICE_M TfRowsL1(const TfLevelArgs& a_, int pg_) : a(a_), pg(pg_) {
+        e = pg / a.L.P; p = pg - e * a.L.P;
+        len = tf_len(a.L, p); start = tf_start(a.L, p);
+    }
+    TF_DEVICE_M void load(int i, double (&row)[2 * TF_MP + 1][TF_NVAR][TF_NVAR]) const {
+#pragma unroll
+        for (int d = 0; d < TF_W; ++d) tf_blk_zero<TF_NVAR>(row[d]);
+        const int64_t s = tf_idx(a.L, pg, i);
+#pragma unroll
+        for (int k = 0; k < TF_NNZ; ++k)
+            row[tf_pat_off[k] + TF_MP][tf_pat_eq[k]][tf_pat_var[k]] =
+                -a.c * a.Jv[(int64_t)k * a.L.plane + s];
+        if (!a.L.periodic) {
+            const int gl = start + i, gr = a.L.N - 1 - gl;
+            if (gl < TF_MP) {
+#pragma unroll
+                for (int d = -TF_MP; d < 0; ++d)
+                    if (d < -gl) {
+#pragma unroll
+                        for (int t = -TF_MP + 1; t <= 0; ++t)
+                            if (t == -gl) {
+#pragma unroll
+                                for (int r = 0; r < TF_NVAR; ++r)
+#pragma unroll
+                                    for (int c = 0; c < TF_NVAR; ++c) {
+                                        row[t + TF_MP][r][c] += row[d + TF_MP][r][c];
+                                        row[d + TF_MP][r][c] = 0.0;
+                                    }
+                            }
+                    }
+            }
+            if (gr < TF_MP) {
+#pragma unroll
+                for (int d = TF_MP; d > 0; --d)
+                    if (d > gr) {
+#pragma unroll
+                        for (int t = TF_MP - 1; t >= 0; --t)
+                            if (t == gr) {
+#pragma unroll
+                                for (int r = 0; r < TF_NVAR; ++r)
+#pragma unroll
+                                    for (int c = 0; c < TF_NVAR; ++c) {
+                                        row[t + TF_MP][r][c] += row[d + TF_MP][r][c];
+                                        row[d + TF_MP][r][c] = 0.0;
+                                    }
+                            }
+                    }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < TF_NVAR; ++r) row[TF_MP][r][r] += 1.0;
+    }
+};
+
+// level >= 2: explicit block-tridiagonal rows [3][b][b]
+template <int BB>
+struct TfRowsBT {
+    static constexpr int B = BB;
+    static constexpr int MP = 1;
+    const TfLevelArgs& a;
+    int pg, e, p, len, start;
+    TF_DEVICE_M TfRowsBT(const TfLevelArgs& a_, int pg_) : a(a_), pg(pg_) {
+        e = pg / a.L.P; p = pg - e * a.L.P;
+        len = tf_len(a.L, p); start = tf_start(a.L, p);
+    }
+    TF_DEVICE_M void load(int i, double (&row)[3][BB][BB]) const {
+        const int64_t s = tf_idx(a.L, pg, i);
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int r = 0; r < BB; ++r)
+#pragma unroll
+                for (int c = 0; c < BB; ++c)
+                    row[d][r][c] = a.Ablk[(int64_t)((d * BB + r) * BB + c) * a.L.plane + s];
+        if (!a.L.periodic) {           // no neighbour beyond the ends
+            const int g = start + i;
+            if (g == 0) tf_blk_zero<BB>(row[0]);
+            if (g == a.L.N - 1) tf_blk_zero<BB>(row[2]);
+        }
+    }
+};
+
+// ---- interior elimination of one chunk in one direction --------------------
+// DIR = +1 walks down (local j <-> node j), DIR = -1 walks up (local j <-> node
+// mI-1-j, offsets mirrored).  SPIKE: also carry the coupling to the separator
+// behind the walk as MP*B extra right-hand sides and emit the V/W tips.
+// STORE (down walk only): keep the normalised pivot rows Ut (and Et when SPIKE)
+// for the back-substitution; the down solve walk stores yt.
+template <class Rows, int DIR, bool SPIKE, bool STORE_U, bool STORE_Y>
+TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
+    constexpr int B = Rows::B, MP = Rows::MP, W = 2 * MP + 1;
+    typedef TfTips<B, MP> Tip;
+    const TfLayout& L = a.L;
+    if (pg >= L.Ptot) return;
+    Rows rows(a, pg);
+    const int len = rows.len;
+    const int mI = len - MP;                      // interior nodes
+    auto node = [&](int j) { return DIR > 0 ? j : mI - 1 - j; };
+
+    // working window: R[q][c] = A(local row j+q, local col j+c)
+    double R[MP + 1][W][B][B];
+    double y[MP + 1][B];
+    double Es[SPIKE ? MP + 1 : 1][SPIKE ? MP : 1][B][B];   // columns: separator behind, local order
+    // normalised rows of the last MP pivots (tips)
+    double Uh[MP][MP][B][B], yh[MP][B];
+    double Eh[SPIKE ? MP : 1][SPIKE ? MP : 1][B][B];
+    bool ok = true;
+
+    auto fetch = [&](int q, int jl) {              // local row jl into window slot q (pivot j = jl - q)
+#pragma unroll
+        for (int c = 0; c < W; ++c) tf_blk_zero<B>(R[q][c]);
+#pragma unroll
+        for (int r = 0; r < B; ++r) y[q][r] = 0.0;
+        if (SPIKE) {
+#pragma unroll
+            for (int t = 0; t < MP; ++t) tf_blk_zero<B>(Es[SPIKE ? q : 0][SPIKE ? t : 0]);
+        }
+        if (jl < mI) {
+            double row[W][B][B];
+            const int i = node(jl);
+            rows.load(i, row);
+#pragma unroll
+            for (int d = -MP; d <= MP; ++d) {
+                const int c = q + d;               // local column relative to the pivot
+                const int dd = DIR > 0 ? d : -d;   // natural offset
+                if (c >= 0) {
+                    if (c < W) tf_blk_copy<B>(R[q][c], row[dd + MP]);
+                } else if (SPIKE) {
+                    // column jl + d < 0: separator behind, local position MP + (jl + d)
+                    const int t = MP + jl + d;
+                    if (t >= 0 && t < MP) tf_blk_copy<B>(Es[SPIKE ? q : 0][SPIKE ? t : 0], row[dd + MP]);
+                }
+            }
+            const int64_t s = tf_idx(L, pg, i);
+#pragma unroll
+            for (int r = 0; r < B; ++r) y[q][r] = a.rhs ? a.rhs[(int64_t)r * L.plane + s] : 0.0;
+        }
+    };
+    // columns c < 0 only occur for the first MP local rows (jl + d < 0); there the
+    // window slot q equals jl (pivot 0), so `c = q + d < 0` is exactly that case.
+
+#pragma unroll
+    for (int q = 0; q < MP; ++q) fetch(q, q);
+
+    for (int j = 0; j < mI; ++j) {
+        fetch(MP, j + MP);
+        double Dinv[B][B];
+        ok = tf_blk_inverse<B>(R[0][0], Dinv) && ok;
+        double Un[MP][B][B], yn[B];
+        double En[SPIKE ? MP : 1][B][B];
+#pragma unroll
+        for (int c = 1; c <= MP; ++c) tf_mm<B>(Un[c - 1], Dinv, R[0][c]);
+        tf_mv<B>(yn, Dinv, y[0]);
+        if (SPIKE) {
+#pragma unroll
+            for (int t = 0; t < MP; ++t) tf_mm<B>(En[t], Dinv, Es[0][t]);
+        }
+#pragma unroll
+        for (int q = 1; q <= MP; ++q) {
+#pragma unroll
+            for (int c = 1; c <= MP; ++c) tf_mm_sub<B>(R[q][c], R[q][0], Un[c - 1]);
+            tf_mv_sub<B>(y[q], R[q][0], yn);
+            if (SPIKE) {
+#pragma unroll
+                for (int t = 0; t < MP; ++t) tf_mm_sub<B>(Es[q][t], R[q][0], En[t]);
+            }
+        }
+        if (STORE_U || STORE_Y) {
+            const int64_t s = tf_idx(L, pg, node(j));
+            if (STORE_U) {
+#pragma unroll
+                for (int c = 0; c < MP; ++c)
+#pragma unroll
+                    for (int r = 0; r < B; ++r)
+#pragma unroll
+                        for (int k = 0; k < B; ++k) {
+                            a.Ut[(int64_t)((c * B + r) * B + k) * L.plane + s] = Un[c][r][k];
+                            if (SPIKE) a.Et[(int64_t)((c * B + r) * B + k) * L.plane + s] = En[SPIKE ? c : 0][r][k];
+                        }
+            }
+            if (STORE_Y) {
+#pragma unroll
+                for (int r = 0; r < B; ++r) a.yt[(int64_t)r * L.plane + s] = yn[r];
+            }
+        }
+        // history of the last MP pivots (slot MP-1 = newest)
+#pragma unroll
+        for (int h = 0; h < MP - 1; ++h) {
+#pragma unroll
+            for (int c = 0; c < MP; ++c) tf_blk_copy<B>(Uh[h][c], Uh[h + 1][c]);
+#pragma unroll
+            for (int r = 0; r < B; ++r) yh[h][r] = yh[h + 1][r];
+            if (SPIKE) {
+#pragma unroll
+                for (int t = 0; t < MP; ++t) tf_blk_copy<B>(Eh[SPIKE ? h : 0][SPIKE ? t : 0], Eh[SPIKE ? h + 1 : 0][SPIKE ? t : 0]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < MP; ++c) tf_blk_copy<B>(Uh[MP - 1][c], Un[c]);
+#pragma unroll
+        for (int r = 0; r < B; ++r) yh[MP - 1][r] = yn[r];
+        if (SPIKE) {
+#pragma unroll
+            for (int t = 0; t < MP; ++t) tf_blk_copy<B>(Eh[SPIKE ? MP - 1 : 0][SPIKE ? t : 0], En[SPIKE ? t : 0]);
+        }
+        // slide the window
+#pragma unroll
+        for (int q = 0; q < MP; ++q) {
+#pragma unroll
+            for (int c = 0; c < W - 1; ++c) tf_blk_copy<B>(R[q][c], R[q + 1][c + 1]);
+            tf_blk_zero<B>(R[q][W - 1]);
+#pragma unroll
+            for (int r = 0; r < B; ++r) y[q][r] = y[q + 1][r];
+            if (SPIKE) {
+#pragma unroll
+                for (int t = 0; t < MP; ++t) tf_blk_copy<B>(Es[SPIKE ? q : 0][SPIKE ? t : 0], Es[SPIKE ? q + 1 : 0][SPIKE ? t : 0]);
+            }
+        }
+    }
+
+    // ---- tips: back-substitute the last MP pivots (local k = 0..MP-1 <-> local
+    // node mI-MP+k); unknowns beyond the interior are the separator ahead.
+    //   x_k = yb_k - sum_t Vb[k][t] s_behind[t] - sum_t Wb[k][t] s_ahead[t]
+    double yb[MP][B];
+    double Vb[SPIKE ? MP : 1][SPIKE ? MP : 1][B][B], Wb[SPIKE ? MP : 1][SPIKE ? MP : 1][B][B];
+#pragma unroll
+    for (int k = MP - 1; k >= 0; --k) {
+#pragma unroll
+        for (int r = 0; r < B; ++r) yb[k][r] = yh[k][r];
+        if (SPIKE) {
+#pragma unroll
+            for (int t = 0; t < MP; ++t) {
+                tf_blk_copy<B>(Vb[SPIKE ? k : 0][SPIKE ? t : 0], Eh[SPIKE ? k : 0][SPIKE ? t : 0]);
+                tf_blk_zero<B>(Wb[SPIKE ? k : 0][SPIKE ? t : 0]);
+            }
+        }
+#pragma unroll
+        for (int c = 1; c <= MP; ++c) {
+            const int kk = k + c;
+            if (kk < MP) {
+                tf_mv_sub<B>(yb[k], Uh[k][c - 1], yb[kk]);
+                if (SPIKE) {
+#pragma unroll
+                    for (int t = 0; t < MP; ++t) {
+                        tf_mm_sub<B>(Vb[SPIKE ? k : 0][SPIKE ? t : 0], Uh[k][c - 1], Vb[SPIKE ? kk : 0][SPIKE ? t : 0]);
+                        tf_mm_sub<B>(Wb[SPIKE ? k : 0][SPIKE ? t : 0], Uh[k][c - 1], Wb[SPIKE ? kk : 0][SPIKE ? t : 0]);
+                    }
+                }
+            } else if (SPIKE) {
+                const int t = kk - MP;                  // separator ahead, local position t
+#pragma unroll
+                for (int r = 0; r < B; ++r)
+#pragma unroll
+                    for (int cc = 0; cc < B; ++cc) Wb[SPIKE ? k : 0][SPIKE ? t : 0][r][cc] += Uh[k][c - 1][r][cc];
+            }
+        }
+    }
+
+    // ---- write in natural orientation
+    double* tips = DIR > 0 ? a.tips_dn : a.tips_up;
+    auto put = [&](int slot, double v) { tips[(int64_t)slot * L.Ptot + pg] = v; };
+#pragma unroll
+    for (int k = 0; k < MP; ++k) {
+        const int kn = DIR > 0 ? k : MP - 1 - k;        // natural tip index
+#pragma unroll
+        for (int r = 0; r < B; ++r) put(Tip::y(kn, r), yb[k][r]);
+        if (SPIKE) {
+#pragma unroll
+            for (int t = 0; t < MP; ++t) {
+                const int tn = DIR > 0 ? t : MP - 1 - t;
+#pragma unroll
+                for (int r = 0; r < B; ++r)
+#pragma unroll
+                    for (int c = 0; c < B; ++c) {
+                        // down: behind = above (V), ahead = below (W); up: the reverse
+                        const double vb = Vb[SPIKE ? k : 0][SPIKE ? t : 0][r][c];
+                        const double wb = Wb[SPIKE ? k : 0][SPIKE ? t : 0][r][c];
+                        put(Tip::V(kn, tn, r, c), DIR > 0 ? vb : wb);
+                        put(Tip::W(kn, tn, r, c), DIR > 0 ? wb : vb);
+                    }
+            }
+        }
+    }
+    if (!ok) *a.status = 1;
+}
+
+// ---- interface (separator) equations -> next level --------------------------
+// MATRIX: build the [3][b][b] block row (factor phase); always builds the rhs.
+template <class Rows, bool MATRIX>
+TF_DEVICE void tfk_asm_body(const TfLevelArgs& a, int pg) {
+    constexpr int B = Rows::B, MP = Rows::MP, W = 2 * MP + 1, BB = MP * B;
+    typedef TfTips<B, MP> Tip;
+    const TfLayout& L = a.L;
+    if (pg >= L.Ptot) return;
+    Rows rows(a, pg);
+    const int e = rows.e, p = rows.p, len = rows.len, mI = len - MP;
+    const bool has_next = L.periodic || p < L.P - 1;
+    const int pn = e * L.P + (p < L.P - 1 ? p + 1 : 0);
+    auto tdn = [&](int slot) { return a.tips_dn[(int64_t)slot * L.Ptot + pg]; };
+    auto tup = [&](int slot) { return a.tips_up[(int64_t)slot * L.Ptot + pn]; };
+
+    // position of this separator in the next level
+    int p2, i2;
+    tf_locate(a.Lnext, p, p2, i2);
+    const int64_t s2 = tf_idx(a.Lnext, e * a.Lnext.P + p2, i2);
+
+#pragma unroll
+    for (int t = 0; t < MP; ++t) {                 // separator node t = chunk node mI + t
+        double row[W][B][B];
+        rows.load(mI + t, row);
+        double sub[MP][B][B], dia[MP][B][B], sup[MP][B][B], g[B];
+#pragma unroll
+        for (int t2 = 0; t2 < MP; ++t2) { tf_blk_zero<B>(sub[t2]); tf_blk_zero<B>(dia[t2]); tf_blk_zero<B>(sup[t2]); }
+        const int64_t s = tf_idx(L, pg, mI + t);
+#pragma unroll
+        for (int r = 0; r < B; ++r) g[r] = a.rhs ? a.rhs[(int64_t)r * L.plane + s] : 0.0;
+#pragma unroll
+        for (int d = -MP; d <= MP; ++d) {
+            const int cn = t + d;                  // column relative to the separator start
+            if (cn >= 0 && cn < MP) {
+                if (MATRIX) {
+#pragma unroll
+                    for (int r = 0; r < B; ++r)
+#pragma unroll
+                        for (int c = 0; c < B; ++c) dia[cn][r][c] += row[d + MP][r][c];
+                }
+            } else if (cn < 0) {                   // bottom tip node kb of the own interior
+                const int kb = cn + MP;
+                double yk[B];
+#pragma unroll
+                for (int r = 0; r < B; ++r) yk[r] = tdn(Tip::y(kb, r));
+                tf_mv_sub<B>(g, row[d + MP], yk);
+                if (MATRIX) {
+#pragma unroll
+                    for (int t2 = 0; t2 < MP; ++t2) {
+                        double Vk[B][B], Wk[B][B];
+#pragma unroll
+                        for (int r = 0; r < B; ++r)
+#pragma unroll
+                            for (int c = 0; c < B; ++c) { Vk[r][c] = tdn(Tip::V(kb, t2, r, c)); Wk[r][c] = tdn(Tip::W(kb, t2, r, c)); }
+                        tf_mm_sub<B>(sub[t2], row[d + MP], Vk);
+                        tf_mm_sub<B>(dia[t2], row[d + MP], Wk);
+                    }
+                }
+            } else if (has_next) {                 // top tip node kt of the next interior
+                const int kt = cn - MP;
+                double yk[B];
+#pragma unroll
+                for (int r = 0; r < B; ++r) yk[r] = tup(Tip::y(kt, r));
+                tf_mv_sub<B>(g, row[d + MP], yk);
+                if (MATRIX) {
+#pragma unroll
+                    for (int t2 = 0; t2 < MP; ++t2) {
+                        double Vk[B][B], Wk[B][B];
+#pragma unroll
+                        for (int r = 0; r < B; ++r)
+#pragma unroll
+                            for (int c = 0; c < B; ++c) { Vk[r][c] = tup(Tip::V(kt, t2, r, c)); Wk[r][c] = tup(Tip::W(kt, t2, r, c)); }
+                        tf_mm_sub<B>(dia[t2], row[d + MP], Vk);
+                        tf_mm_sub<B>(sup[t2], row[d + MP], Wk);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < B; ++r) a.rhsnext[(int64_t)(t * B + r) * a.Lnext.plane + s2] = g[r];
+        if (MATRIX) {
+#pragma unroll
+            for (int t2 = 0; t2 < MP; ++t2)
+#pragma unroll
+                for (int r = 0; r < B; ++r)
+#pragma unroll
+                    for (int c = 0; c < B; ++c) {
+                        const int rr = t * B + r, cc = t2 * B + c;
+                        a.Anext[(int64_t)((0 * BB + rr) * BB + cc) * a.Lnext.plane + s2] = sub[t2][r][c];
+                        a.Anext[(int64_t)((1 * BB + rr) * BB + cc) * a.Lnext.plane + s2] = dia[t2][r][c];
+                        a.Anext[(int64_t)((2 * BB + rr) * BB + cc) * a.Lnext.plane + s2] = sup[t2][r][c];
+                    }
+        }
+    }
+}
+
+// ---- back-substitution of one chunk (separators known) ----------------------
+template <class Rows>
+TF_DEVICE void tfk_backsub_body(const TfLevelArgs& a, int pg) {
+    constexpr int B = Rows::B, MP = Rows::MP;
+    const TfLayout& L = a.L;
+    if (pg >= L.Ptot) return;
+    const int e = pg / L.P, p = pg - e * L.P;
+    const int len = tf_len(L, p), mI = len - MP;
+    const bool has_above = L.periodic || p > 0;
+    const int pa = p > 0 ? p - 1 : L.P - 1;
+    double sa[MP][B], xn[MP][B];
+    {
+        int p2, i2;
+        tf_locate(a.Lnext, p, p2, i2);
+        const int64_t s2 = tf_idx(a.Lnext, e * a.Lnext.P + p2, i2);
+#pragma unroll
+        for (int t = 0; t < MP; ++t)
+#pragma unroll
+            for (int r = 0; r < B; ++r) xn[t][r] = a.xnext[(int64_t)(t * B + r) * a.Lnext.plane + s2];
+        tf_locate(a.Lnext, pa, p2, i2);
+        const int64_t s2a = tf_idx(a.Lnext, e * a.Lnext.P + p2, i2);
+#pragma unroll
+        for (int t = 0; t < MP; ++t)
+#pragma unroll
+            for (int r = 0; r < B; ++r) sa[t][r] = has_above ? a.xnext[(int64_t)(t * B + r) * a.Lnext.plane + s2a] : 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < MP; ++t) {
+        const int64_t s = tf_idx(L, pg, mI + t);
+#pragma unroll
+        for (int r = 0; r < B; ++r) a.x[(int64_t)r * L.plane + s] = xn[t][r];
+    }
+    for (int j = mI - 1; j >= 0; --j) {
+        const int64_t s = tf_idx(L, pg, j);
+        double x[B];
+#pragma unroll
+        for (int r = 0; r < B; ++r) x[r] = a.yt[(int64_t)r * L.plane + s];
+#pragma unroll
+        for (int c = 0; c < MP; ++c) {
+            double Ub[B][B], Eb[B][B];
+#pragma unroll
+            for (int r = 0; r < B; ++r)
+#pragma unroll
+                for (int k = 0; k < B; ++k) {
+                    Ub[r][k] = a.Ut[(int64_t)((c * B + r) * B + k) * L.plane + s];
+                    Eb[r][k] = a.Et[(int64_t)((c * B + r) * B + k) * L.plane + s];
+                }
+            tf_mv_sub<B>(x, Ub, xn[c]);
+            tf_mv_sub<B>(x, Eb, sa[c]);
+        }
+#pragma unroll
+        for (int c = MP - 1; c > 0; --c)
+#pragma unroll
+            for (int r = 0; r < B; ++r) xn[c][r] = xn[c - 1][r];
+#pragma unroll
+        for (int r = 0; r < B; ++r) { xn[0][r] = x[r]; a.x[(int64_t)r * L.plane + s] = x[r]; }
+    }
+}
+
+// ---- last level: one b x b block per system ---------------------------------
+template <int BB, bool FACTOR>
+TF_DEVICE void tfk_top_body(const TfTopArgs& a, int e) {
+    if (e >= a.nsys) return;
+    if (FACTOR) {
+        double D[BB][BB], Di[BB][BB];
+#pragma unroll
+        for (int r = 0; r < BB; ++r)
+#pragma unroll
+            for (int c = 0; c < BB; ++c)
+                D[r][c] = a.A[(int64_t)((0 * BB + r) * BB + c) * a.nsys + e]
+                        + a.A[(int64_t)((1 * BB + r) * BB + c) * a.nsys + e]
+                        + a.A[(int64_t)((2 * BB + r) * BB + c) * a.nsys + e];
+        if (!tf_blk_inverse<BB>(D, Di)) *a.status = 1;
+#pragma unroll
+        for (int r = 0; r < BB; ++r)
+#pragma unroll
+            for (int c = 0; c < BB; ++c) a.Ainv[(int64_t)(r * BB + c) * a.nsys + e] = Di[r][c];
+    } else {
+        double Di[BB][BB], g[BB], x[BB];
+#pragma unroll
+        for (int r = 0; r < BB; ++r) {
+            g[r] = a.rhs[(int64_t)r * a.nsys + e];
+#pragma unroll
+            for (int c = 0; c < BB; ++c) Di[r][c] = a.Ainv[(int64_t)(r * BB + c) * a.nsys + e];
+        }
+        tf_mv<BB>(x, Di, g);
+#pragma unroll
+        for (int r = 0; r < BB; ++r) a.x[(int64_t)r * a.nsys + e] = x[r];
+    }
+}

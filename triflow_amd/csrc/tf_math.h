@@ -1,0 +1,40 @@
+// Scalar arithmetic helpers used by the generated stencil bodies and the kernel
+// skeletons.  Included before the generated per-model code.
+#pragma once
+#ifndef TF_DEVICE
+#error "define TF_DEVICE before including tf_math.h"
+#endif
+#ifndef TF_DEVICE_M          // qualifier of in-class functions
+#define TF_DEVICE_M TF_DEVICE
+#endif
+
+// ---------------------------------------------------------------- arithmetic
+// The stencil bodies are compiled with -ffp-contract=off and mirror the
+// operation tree NumPy evaluates, so F and J agree bit for bit with the
+// reference's numpy-compiler path for + - * / sqrt and integer powers.
+TF_DEVICE double tf_sq(double a) { return a * a; }
+
+// correctly rounded (up to double rounding, ~2^-50) small integer powers via
+// double-double products -- what a correctly rounded libm pow() returns
+TF_DEVICE double tf_powi(double x, int n) {
+    bool neg = n < 0;
+    if (neg) n = -n;
+    double hi = 1.0, lo = 0.0;
+    for (int k = 0; k < n; ++k) {
+        double p = hi * x;
+        double e = __builtin_fma(hi, x, -p);
+        e = __builtin_fma(lo, x, e);
+        double s = p + e;
+        lo = e - (s - p);
+        hi = s;
+    }
+    double r = hi + lo;
+    return neg ? 1.0 / r : r;
+}
+TF_DEVICE double tf_max(double a, double b) { return (a > b || a != a) ? a : b; }   // np.maximum
+TF_DEVICE double tf_min(double a, double b) { return (a < b || a != a) ? a : b; }   // np.minimum
+TF_DEVICE double tf_sign(double a) { return a > 0 ? 1.0 : (a < 0 ? -1.0 : a); }
+TF_DEVICE double tf_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+TF_DEVICE double tf_abs(double a) { return __builtin_fabs(a); }
+TF_DEVICE bool tf_finite(double a) { return (a - a) == 0.0; }
+

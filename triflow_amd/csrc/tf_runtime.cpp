@@ -1,0 +1,746 @@
+// Host runtime of libtriflow_hip: the C ABI of include/triflow_hip.h.
+//
+// Owns the device memory, the HIP stream, the per-model code object and the
+// orchestration of the kernels in tf_kernels.h:
+//   * F / F+J stencil sweep on a resident state      (compilers.py:227-332)
+//   * multi-level block-banded factor / solve         (SuperLU call sites schemes.py:149,557)
+//   * the time-step drivers Theta / Rosenbrock-Wanner / BDF-2, written so that
+//     the vector algebra follows the reference's expressions term by term
+//     (schemes.py:142-174, 548-559)
+// No compute happens on the host; the only host<->device traffic is what the
+// caller asks for through tf_set_* / tf_get_*.
+#include "../../include/triflow_hip.h"
+#include "tf_args.h"
+#include "tf_backend.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+#define TF_API_BEGIN try {
+#define TF_API_END                                               \
+    return 0;                                                    \
+    }                                                            \
+    catch (const std::exception& ex) { g_last_error = ex.what(); return 1; } \
+    catch (...) { g_last_error = "unknown error"; return 1; }
+
+void require(bool cond, const char* msg) {
+    if (!cond) throw std::invalid_argument(msg);
+}
+
+TfLayout make_layout(int nsys, int N, int P, int periodic) {
+    TfLayout L;
+    L.nsys = nsys; L.N = N; L.P = P;
+    L.mbase = N / P; L.rem = N % P;
+    L.M = L.mbase + (L.rem > 0 ? 1 : 0);
+    L.Ptot = nsys * P;
+    L.periodic = periodic;
+    L.plane = (int64_t)L.M * L.Ptot;
+    return L;
+}
+
+struct DevBuf {
+    double* p = nullptr;
+    size_t n = 0;
+    void alloc(size_t count, int64_t& total) {
+        release();
+        n = count;
+        p = (double*)tfb::dev_alloc(std::max<size_t>(count, 1) * sizeof(double));
+        total += (int64_t)(std::max<size_t>(count, 1) * sizeof(double));
+    }
+    void release() { if (p) tfb::dev_free(p); p = nullptr; n = 0; }
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+};
+
+struct Level {
+    TfLayout L;
+    int B = 0, MP = 0;
+    DevBuf Ablk, rhs, x, Ut, Et, yt, tips_dn, tips_up;
+};
+
+}  // namespace
+
+// enum values of tf_kernels.h (kept in sync by tests/test_abi.py)
+enum {
+    TF_VEC_SUM = 0, TF_VEC_LIN2 = 1, TF_VEC_THETA_RHS = 2, TF_VEC_MAXABS = 3, TF_VEC_COPY = 4,
+    TF_VEC_BDF2_RHS = 5, TF_VEC_ADD = 6, TF_VEC_RESID = 7
+};
+
+struct tf_model {
+    tf_model_spec spec;
+    tfb::Module* module = nullptr;
+    ~tf_model() { tfb::module_unload(module); }
+};
+
+struct tf_solver {
+    tf_model* model = nullptr;
+    tf_model_spec spec;
+    int64_t N = 0;
+    int nsys = 1, periodic = 0, nstate = 3, refine = 0;
+    TfLayout L1;
+    tfb::Stream* stream = nullptr;
+    int64_t bytes = 0;
+
+    std::vector<std::unique_ptr<DevBuf>> state;     // [nstate] x nvar planes
+    DevBuf helpers, parvec, parsca, dx, xcoord;
+    DevBuf F, Jv, Wstage, Wsum, Wjv, Wrhs, Wres, Wdel, Uprev, K[TF_MAX_TERMS];
+    DevBuf staging;
+    DevBuf red;            // reduction scalars
+    int* status = nullptr;
+    std::vector<std::unique_ptr<Level>> levels;     // chunk levels; the last one has P == 1
+    Level top;             // single-node system per ensemble member
+    DevBuf topAinv;
+    double factor_c = 0.0;
+    bool have_factor = false, have_jac = false;
+
+    // declarative Dirichlet hook
+    int ndir = 0;
+    int *dir_var = nullptr, *dir_node = nullptr;
+    DevBuf dir_val;
+
+    // BDF-2 history
+    bool bdf_have_prev = false;
+    double bdf_dt_prev = 0.0;
+
+    // timing
+    bool timing = false;
+    struct Stamp { int kernel; tfb::Event *a, *b; };
+    std::vector<Stamp> stamps;
+    std::vector<tfb::Event*> event_pool;
+    double time_ms[TFK_COUNT] = {0};
+    int64_t time_n[TFK_COUNT] = {0};
+
+    ~tf_solver() {
+        for (auto& st : stamps) { tfb::event_destroy(st.a); tfb::event_destroy(st.b); }
+        for (auto* e : event_pool) tfb::event_destroy(e);
+        if (status) tfb::dev_free(status);
+        if (dir_var) tfb::dev_free(dir_var);
+        if (dir_node) tfb::dev_free(dir_node);
+        tfb::stream_destroy(stream);
+    }
+
+    int64_t plane() const { return L1.plane; }
+    int64_t vecn() const { return (int64_t)spec.nvar * L1.plane; }
+    double* st(int slot) {
+        if (slot < 0 || slot >= nstate) throw std::invalid_argument("state slot out of range");
+        return state[slot]->p;
+    }
+
+    // ------------------------------------------------------------ launching
+    tfb::Event* get_event() {
+        if (!event_pool.empty()) { auto* e = event_pool.back(); event_pool.pop_back(); return e; }
+        return tfb::event_create();
+    }
+    void launch(int kernel, unsigned gx, unsigned gy, unsigned block, const void* args, size_t sz) {
+        if (timing) {
+            Stamp stp{kernel, get_event(), get_event()};
+            tfb::event_record(stp.a, stream);
+            tfb::launch(model->module, kernel, gx, gy, block, args, sz, stream);
+            tfb::event_record(stp.b, stream);
+            stamps.push_back(stp);
+        } else {
+            tfb::launch(model->module, kernel, gx, gy, block, args, sz, stream);
+        }
+    }
+    void collect_timing() {
+        if (stamps.empty()) return;
+        tfb::stream_sync(stream);
+        for (auto& stp : stamps) {
+            time_ms[stp.kernel] += tfb::event_elapsed_ms(stp.a, stp.b);
+            time_n[stp.kernel] += 1;
+            event_pool.push_back(stp.a);
+            event_pool.push_back(stp.b);
+        }
+        stamps.clear();
+    }
+    static unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+    // ------------------------------------------------------ elementary steps
+    void vec(int op, double* out, const double* base, int nterms, const double* const* xs,
+             const double* cs, int64_t n = -1) {
+        TfVecArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.n = n < 0 ? vecn() : n;
+        a.nterms = nterms; a.op = op; a.out = out; a.base = base; a.red = red.p;
+        for (int t = 0; t < nterms; ++t) { a.x[t] = xs[t]; a.c[t] = cs ? cs[t] : 1.0; }
+        unsigned grid = std::min<unsigned>(cdiv(a.n, 256), 2048u);
+        launch(op == TF_VEC_MAXABS ? TFK_VEC_MAXABS : TFK_VEC, std::max(grid, 1u), 1, 256, &a, sizeof(a));
+    }
+
+    void perm(int mode, const double* src, double* dst, int ncomp) {
+        TfPermArgs a;
+        a.L = L1; a.src = src; a.dst = dst; a.ncomp = ncomp; a.mode = mode;
+        launch(TFK_PERM, cdiv((int64_t)nsys * N, 256), 1, 256, &a, sizeof(a));
+    }
+    void ensure_staging(size_t count) {
+        if (staging.n < count) staging.alloc(count, bytes);
+    }
+    // host [ncomp][nsys][N] -> planes
+    void upload_planes(const double* host, double* planes, int ncomp) {
+        size_t cnt = (size_t)ncomp * nsys * N;
+        ensure_staging(cnt);
+        tfb::h2d(staging.p, host, cnt * sizeof(double), stream);
+        perm(0 /*IN_SOA*/, staging.p, planes, ncomp);
+    }
+    void download_planes(const double* planes, double* host, int ncomp) {
+        size_t cnt = (size_t)ncomp * nsys * N;
+        ensure_staging(cnt);
+        perm(1 /*OUT_SOA*/, planes, staging.p, ncomp);
+        tfb::d2h(host, staging.p, cnt * sizeof(double), stream);
+    }
+    void upload_aos(const double* host, double* planes, int ncomp) {
+        size_t cnt = (size_t)ncomp * nsys * N;
+        ensure_staging(cnt);
+        tfb::h2d(staging.p, host, cnt * sizeof(double), stream);
+        perm(3 /*IN_AOS*/, staging.p, planes, ncomp);
+    }
+    void download_aos(const double* planes, double* host, int ncomp) {
+        size_t cnt = (size_t)ncomp * nsys * N;
+        ensure_staging(cnt);
+        perm(2 /*OUT_AOS*/, planes, staging.p, ncomp);
+        tfb::d2h(host, staging.p, cnt * sizeof(double), stream);
+    }
+
+    void apply_dirichlet(double* fields) {
+        if (ndir == 0) return;
+        TfDirichletArgs a;
+        a.L = L1; a.fields = fields; a.n = ndir; a.var = dir_var; a.node = dir_node; a.value = dir_val.p;
+        launch(TFK_DIRICHLET, cdiv((int64_t)ndir * nsys, 64), 1, 64, &a, sizeof(a));
+    }
+
+    void sweep(const double* fields, bool with_j) {
+        TfSweepArgs a;
+        a.L = L1; a.fields = fields; a.helpers = helpers.p; a.parvec = parvec.p; a.parsca = parsca.p;
+        a.dx = dx.p; a.xcoord = xcoord.p; a.F = F.p; a.Jv = Jv.p; a.with_j = with_j ? 1 : 0;
+        unsigned gx = cdiv(L1.Ptot, spec.sweep_block), gy = cdiv(L1.M, spec.seg);
+        launch(with_j ? TFK_SWEEP_FJ : TFK_SWEEP_F, gx, gy, spec.sweep_block, &a, sizeof(a));
+        if (with_j) { have_jac = true; have_factor = false; }
+    }
+    void spmv(const double* v, double* y, double scale) {
+        TfSpmvArgs a;
+        a.L = L1; a.Jv = Jv.p; a.v = v; a.y = y; a.scale = scale;
+        unsigned gx = cdiv(L1.Ptot, spec.sweep_block), gy = cdiv(L1.M, spec.seg);
+        launch(TFK_SPMV, gx, gy, spec.sweep_block, &a, sizeof(a));
+    }
+
+    // -------------------------------------------------------- banded solver
+    Level& next_of(size_t l) { return l + 1 < levels.size() ? *levels[l + 1] : top; }
+    TfLevelArgs level_args(size_t l, const double* rhs1, double* x1) {
+        Level& lv = *levels[l];
+        Level& nx = next_of(l);
+        TfLevelArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.L = lv.L; a.Jv = Jv.p; a.c = factor_c; a.Ablk = lv.Ablk.p;
+        a.rhs = l == 0 ? rhs1 : lv.rhs.p;
+        a.x = l == 0 ? x1 : lv.x.p;
+        a.Ut = lv.Ut.p; a.Et = lv.Et.p; a.yt = lv.yt.p;
+        a.tips_dn = lv.tips_dn.p; a.tips_up = lv.tips_up.p;
+        a.Lnext = nx.L; a.Anext = nx.Ablk.p; a.rhsnext = nx.rhs.p; a.xnext = nx.x.p;
+        a.status = status;
+        return a;
+    }
+    void factor(double c) {
+        if (!have_jac) throw std::runtime_error("tf_factor: no Jacobian evaluated yet (call tf_eval with_j=1)");
+        factor_c = c;
+        for (size_t l = 0; l < levels.size(); ++l) {
+            TfLevelArgs a = level_args(l, nullptr, nullptr);
+            a.rhs = nullptr;
+            unsigned gx = cdiv(a.L.Ptot, 64);
+            launch(l == 0 ? TFK_L1_FACTOR : TFK_BT_FACTOR, gx, 2, 64, &a, sizeof(a));
+            launch(l == 0 ? TFK_L1_ASM_MAT : TFK_BT_ASM_MAT, gx, 1, 64, &a, sizeof(a));
+        }
+        TfTopArgs t;
+        t.nsys = nsys; t.A = top.Ablk.p; t.rhs = top.rhs.p; t.Ainv = topAinv.p; t.x = top.x.p; t.status = status;
+        launch(TFK_TOP_FACTOR, cdiv(nsys, 64), 1, 64, &t, sizeof(t));
+        have_factor = true;
+    }
+    void solve_once(const double* rhs1, double* x1) {
+        for (size_t l = 0; l < levels.size(); ++l) {
+            TfLevelArgs a = level_args(l, rhs1, x1);
+            unsigned gx = cdiv(a.L.Ptot, 64);
+            launch(l == 0 ? TFK_L1_SOLVE : TFK_BT_SOLVE, gx, 2, 64, &a, sizeof(a));
+            launch(l == 0 ? TFK_L1_ASM_RHS : TFK_BT_ASM_RHS, gx, 1, 64, &a, sizeof(a));
+        }
+        TfTopArgs t;
+        t.nsys = nsys; t.A = top.Ablk.p; t.rhs = top.rhs.p; t.Ainv = topAinv.p; t.x = top.x.p; t.status = status;
+        launch(TFK_TOP_SOLVE, cdiv(nsys, 64), 1, 64, &t, sizeof(t));
+        for (size_t l = levels.size(); l-- > 0;) {
+            TfLevelArgs a = level_args(l, rhs1, x1);
+            launch(l == 0 ? TFK_L1_BACKSUB : TFK_BT_BACKSUB, cdiv(a.L.Ptot, 64), 1, 64, &a, sizeof(a));
+        }
+    }
+    // x = (I - c J)^-1 rhs, optionally polished by iterative refinement
+    void solve(const double* rhs1, double* x1) {
+        if (!have_factor) throw std::runtime_error("tf_solve: matrix not factorised");
+        solve_once(rhs1, x1);
+        for (int it = 0; it < refine; ++it) {
+            spmv(x1, Wjv.p, factor_c);                               // c J x
+            const double* xs[3] = {rhs1, x1, Wjv.p};
+            vec(TF_VEC_RESID, Wres.p, nullptr, 3, xs, nullptr);      // r = (b - x) + c J x
+            solve_once(Wres.p, Wdel.p);
+            const double* ys[2] = {x1, Wdel.p};
+            vec(TF_VEC_ADD, x1, nullptr, 2, ys, nullptr);
+        }
+    }
+
+    void check_status() {
+        int flag = 0;
+        tfb::d2h(&flag, status, sizeof(int), stream);
+        if (flag != 0) {
+            tfb::memset0(status, sizeof(int), stream);
+            throw std::runtime_error("banded solver: singular or non-finite pivot block");
+        }
+    }
+};
+
+extern "C" {
+
+const char* tf_last_error(void) { return g_last_error.c_str(); }
+
+int tf_runtime_info(int32_t* is_device_build, int32_t* device_count) {
+    TF_API_BEGIN
+    if (is_device_build) *is_device_build = tfb::is_device_build() ? 1 : 0;
+    if (device_count) *device_count = tfb::device_count();
+    TF_API_END
+}
+
+int tf_kernel_count(void) { return TFK_COUNT; }
+const char* tf_kernel_name(int32_t kernel) {
+    static const char* names[TFK_COUNT] = TF_KERNEL_NAMES;
+    return (kernel >= 0 && kernel < TFK_COUNT) ? names[kernel] : "";
+}
+
+int tf_model_create(const tf_model_spec* spec, const void* code, size_t size, tf_model** out) {
+    TF_API_BEGIN
+    require(spec && out, "tf_model_create: null argument");
+    require(spec->nvar >= 1 && spec->nvar + spec->nh <= TF_MAX_FIELDS, "tf_model_create: bad field count");
+    require(spec->npar >= 0 && spec->npar <= TF_MAX_PARS, "tf_model_create: bad parameter count");
+    require(spec->mp >= 1 && spec->seg >= 1 && spec->sweep_block >= 64, "tf_model_create: bad stencil constants");
+    std::unique_ptr<tf_model> m(new tf_model());
+    m->spec = *spec;
+    m->module = tfb::module_load(code, size);
+    *out = m.release();
+    TF_API_END
+}
+
+void tf_model_destroy(tf_model* model) { delete model; }
+
+int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
+                     const tf_solver_opts* opts, tf_solver** out) {
+    TF_API_BEGIN
+    require(model && out, "tf_solver_create: null argument");
+    const tf_model_spec& sp = model->spec;
+    require(nsys >= 1, "tf_solver_create: nsys must be >= 1");
+    require(N >= 2 * sp.mp + 1, "tf_solver_create: the grid must hold at least one stencil window (N >= 2*mp+1)");
+    require(N * (int64_t)nsys < (int64_t)1 << 31, "tf_solver_create: too many nodes for 32-bit chunk indices");
+    std::unique_ptr<tf_solver> s(new tf_solver());
+    s->model = model; s->spec = sp; s->N = N; s->nsys = nsys; s->periodic = periodic ? 1 : 0;
+    int m1 = opts && opts->m1 > 0 ? opts->m1 : 32;
+    int mup = opts && opts->m_upper > 0 ? opts->m_upper : 8;
+    s->nstate = opts && opts->nstate > 0 ? opts->nstate : 3;
+    s->refine = opts && opts->refine > 0 ? opts->refine : 0;
+    if (opts && opts->device >= 0) tfb::set_device(opts->device);
+    m1 = std::max(m1, 2 * sp.mp);
+    mup = std::max(mup, 2);
+    s->stream = tfb::stream_create();
+
+    // ---- level plan: chunk levels until a single chunk is left, then the top block
+    const int b2 = sp.mp * sp.nvar;
+    {
+        int n = (int)N, B = sp.nvar, MP = sp.mp, m = m1;
+        while (true) {
+            int P = std::max(1, n / m);
+            std::unique_ptr<Level> lv(new Level());
+            lv->L = make_layout(nsys, n, P, s->periodic);
+            lv->B = B; lv->MP = MP;
+            s->levels.push_back(std::move(lv));
+            if (P == 1) break;
+            n = P; B = b2; MP = 1; m = mup;
+        }
+        s->top.L = make_layout(nsys, 1, 1, s->periodic);
+        s->top.B = b2; s->top.MP = 1;
+    }
+    s->L1 = s->levels[0]->L;
+    const int64_t plane = s->L1.plane;
+
+    // ---- memory
+    int64_t& tot = s->bytes;
+    for (int i = 0; i < s->nstate; ++i) {
+        s->state.emplace_back(new DevBuf());
+        s->state.back()->alloc((size_t)sp.nvar * plane, tot);
+    }
+    s->helpers.alloc((size_t)sp.nh * plane, tot);
+    if (sp.parvec_mask) s->parvec.alloc((size_t)sp.npar * plane, tot); else s->parvec.alloc(1, tot);
+    s->parsca.alloc((size_t)std::max(sp.npar, 1) * nsys, tot);
+    s->dx.alloc(nsys, tot);
+    if (sp.uses_x) s->xcoord.alloc(plane, tot); else s->xcoord.alloc(1, tot);
+    s->F.alloc((size_t)sp.nvar * plane, tot);
+    s->Jv.alloc((size_t)std::max(sp.nnz, 1) * plane, tot);
+    DevBuf* work[] = {&s->Wstage, &s->Wsum, &s->Wjv, &s->Wrhs, &s->Wres, &s->Wdel, &s->Uprev};
+    for (DevBuf* w : work) w->alloc((size_t)sp.nvar * plane, tot);
+    for (int i = 0; i < TF_MAX_TERMS; ++i) s->K[i].alloc(i < 6 ? (size_t)sp.nvar * plane : 1, tot);
+    s->red.alloc(8, tot);
+    s->status = (int*)tfb::dev_alloc(sizeof(int));
+    for (size_t l = 0; l < s->levels.size(); ++l) {
+        Level& lv = *s->levels[l];
+        const int B = lv.B, MP = lv.MP;
+        const int64_t pl = lv.L.plane;
+        lv.Ut.alloc((size_t)MP * B * B * pl, tot);
+        lv.Et.alloc((size_t)MP * B * B * pl, tot);
+        lv.yt.alloc((size_t)B * pl, tot);
+        const size_t tipsz = (size_t)(MP * B + 2 * MP * MP * B * B) * lv.L.Ptot;
+        lv.tips_dn.alloc(tipsz, tot);
+        lv.tips_up.alloc(tipsz, tot);
+        if (l > 0) {
+            lv.Ablk.alloc((size_t)3 * B * B * pl, tot);
+            lv.rhs.alloc((size_t)B * pl, tot);
+            lv.x.alloc((size_t)B * pl, tot);
+        }
+    }
+    s->top.Ablk.alloc((size_t)3 * b2 * b2 * nsys, tot);
+    s->top.rhs.alloc((size_t)b2 * nsys, tot);
+    s->top.x.alloc((size_t)b2 * nsys, tot);
+    s->topAinv.alloc((size_t)b2 * b2 * nsys, tot);
+    *out = s.release();
+    TF_API_END
+}
+
+void tf_solver_destroy(tf_solver* solver) {
+    if (!solver) return;
+    try { tfb::stream_sync(solver->stream); } catch (...) {}
+    delete solver;
+}
+
+int tf_solver_describe(tf_solver* s, int32_t* nlevels, int32_t* chunks, int32_t max_levels,
+                       int64_t* device_bytes) {
+    TF_API_BEGIN
+    require(s, "null solver");
+    if (nlevels) *nlevels = (int32_t)s->levels.size();
+    if (chunks)
+        for (size_t l = 0; l < s->levels.size() && (int)l < max_levels; ++l) chunks[l] = s->levels[l]->L.P;
+    if (device_bytes) *device_bytes = s->bytes;
+    TF_API_END
+}
+
+// ------------------------------------------------------------------- inputs
+int tf_set_state(tf_solver* s, int32_t slot, int32_t first, int32_t nv, const double* host) {
+    TF_API_BEGIN
+    require(s && host, "null argument");
+    require(first >= 0 && nv >= 1 && first + nv <= s->spec.nvar, "tf_set_state: variable range");
+    s->upload_planes(host, s->st(slot) + (int64_t)first * s->plane(), nv);
+    TF_API_END
+}
+int tf_get_state(tf_solver* s, int32_t slot, int32_t first, int32_t nv, double* host) {
+    TF_API_BEGIN
+    require(s && host, "null argument");
+    require(first >= 0 && nv >= 1 && first + nv <= s->spec.nvar, "tf_get_state: variable range");
+    s->download_planes(s->st(slot) + (int64_t)first * s->plane(), host, nv);
+    s->check_status();
+    TF_API_END
+}
+int tf_set_state_flat(tf_solver* s, int32_t slot, const double* uflat) {
+    TF_API_BEGIN
+    require(s && uflat, "null argument");
+    s->upload_aos(uflat, s->st(slot), s->spec.nvar);
+    TF_API_END
+}
+int tf_get_state_flat(tf_solver* s, int32_t slot, double* uflat) {
+    TF_API_BEGIN
+    require(s && uflat, "null argument");
+    s->download_aos(s->st(slot), uflat, s->spec.nvar);
+    s->check_status();
+    TF_API_END
+}
+int tf_copy_state(tf_solver* s, int32_t src, int32_t dst) {
+    TF_API_BEGIN
+    require(s, "null solver");
+    if (src != dst) tfb::d2d(s->st(dst), s->st(src), (size_t)s->vecn() * sizeof(double), s->stream);
+    TF_API_END
+}
+int tf_set_helpers(tf_solver* s, int32_t first, int32_t count, const double* host) {
+    TF_API_BEGIN
+    require(s && host, "null argument");
+    require(first >= 0 && count >= 1 && first + count <= s->spec.nh, "tf_set_helpers: range");
+    s->upload_planes(host, s->helpers.p + (int64_t)first * s->plane(), count);
+    TF_API_END
+}
+int tf_set_param_scalar(tf_solver* s, int32_t k, const double* values) {
+    TF_API_BEGIN
+    require(s && values, "null argument");
+    require(k >= 0 && k < s->spec.npar, "tf_set_param_scalar: index");
+    require(!((s->spec.parvec_mask >> k) & 1u), "tf_set_param_scalar: parameter compiled as per-node array");
+    tfb::h2d(s->parsca.p + (int64_t)k * s->nsys, values, sizeof(double) * s->nsys, s->stream);
+    TF_API_END
+}
+int tf_set_param_vector(tf_solver* s, int32_t k, const double* host) {
+    TF_API_BEGIN
+    require(s && host, "null argument");
+    require(k >= 0 && k < s->spec.npar, "tf_set_param_vector: index");
+    require((s->spec.parvec_mask >> k) & 1u, "tf_set_param_vector: parameter compiled as scalar");
+    s->upload_planes(host, s->parvec.p + (int64_t)k * s->plane(), 1);
+    TF_API_END
+}
+int tf_set_dx(tf_solver* s, const double* dxv) {
+    TF_API_BEGIN
+    require(s && dxv, "null argument");
+    tfb::h2d(s->dx.p, dxv, sizeof(double) * s->nsys, s->stream);
+    TF_API_END
+}
+int tf_set_x(tf_solver* s, const double* x) {
+    TF_API_BEGIN
+    require(s && x, "null argument");
+    if (s->spec.uses_x) s->upload_planes(x, s->xcoord.p, 1);
+    TF_API_END
+}
+int tf_set_dirichlet(tf_solver* s, int32_t n, const int32_t* var, const int64_t* node, const double* value) {
+    TF_API_BEGIN
+    require(s, "null solver");
+    require(n >= 0, "tf_set_dirichlet: n");
+    if (s->dir_var) { tfb::dev_free(s->dir_var); s->dir_var = nullptr; }
+    if (s->dir_node) { tfb::dev_free(s->dir_node); s->dir_node = nullptr; }
+    s->ndir = 0;
+    if (n > 0) {
+        require(var && node && value, "tf_set_dirichlet: null arrays");
+        std::vector<int> nodes(n);
+        for (int i = 0; i < n; ++i) {
+            require(var[i] >= 0 && var[i] < s->spec.nvar, "tf_set_dirichlet: variable index");
+            require(node[i] >= -s->N && node[i] < s->N, "tf_set_dirichlet: node index");
+            nodes[i] = (int)node[i];
+        }
+        s->dir_var = (int*)tfb::dev_alloc(sizeof(int) * n);
+        s->dir_node = (int*)tfb::dev_alloc(sizeof(int) * n);
+        int64_t dummy = 0;
+        s->dir_val.alloc(n, dummy);
+        tfb::h2d(s->dir_var, var, sizeof(int) * n, s->stream);
+        tfb::h2d(s->dir_node, nodes.data(), sizeof(int) * n, s->stream);
+        tfb::h2d(s->dir_val.p, value, sizeof(double) * n, s->stream);
+        s->ndir = n;
+    }
+    TF_API_END
+}
+
+// --------------------------------------------------------------- seam #1
+int tf_eval(tf_solver* s, int32_t slot, int32_t with_j) {
+    TF_API_BEGIN
+    require(s, "null solver");
+    s->sweep(s->st(slot), with_j != 0);
+    TF_API_END
+}
+int tf_get_F(tf_solver* s, double* Fh) {
+    TF_API_BEGIN
+    require(s && Fh, "null argument");
+    s->download_aos(s->F.p, Fh, s->spec.nvar);
+    TF_API_END
+}
+int tf_get_J(tf_solver* s, double* Jh) {
+    TF_API_BEGIN
+    require(s && Jh, "null argument");
+    require(s->have_jac, "tf_get_J: no Jacobian evaluated yet");
+    if (s->spec.nnz > 0) s->download_aos(s->Jv.p, Jh, s->spec.nnz);
+    TF_API_END
+}
+
+// --------------------------------------------------------------- seam #3
+int tf_factor(tf_solver* s, double c) {
+    TF_API_BEGIN
+    require(s, "null solver");
+    s->factor(c);
+    TF_API_END
+}
+int tf_solve(tf_solver* s, const double* rhs_flat, double* x_flat) {
+    TF_API_BEGIN
+    require(s && rhs_flat && x_flat, "null argument");
+    s->upload_aos(rhs_flat, s->Wrhs.p, s->spec.nvar);
+    s->solve(s->Wrhs.p, s->Wstage.p);
+    s->download_aos(s->Wstage.p, x_flat, s->spec.nvar);
+    s->check_status();
+    TF_API_END
+}
+int tf_matvec(tf_solver* s, const double* v_flat, double* y_flat) {
+    TF_API_BEGIN
+    require(s && v_flat && y_flat, "null argument");
+    require(s->have_jac, "tf_matvec: no Jacobian evaluated yet");
+    s->upload_aos(v_flat, s->Wsum.p, s->spec.nvar);
+    s->spmv(s->Wsum.p, s->Wjv.p, 1.0);
+    s->download_aos(s->Wjv.p, y_flat, s->spec.nvar);
+    TF_API_END
+}
+
+// --------------------------------------------------------------- seam #2
+// Theta scheme, reference schemes.py:548-559:
+//   fields = copy; hook(t); F, J; B = dt*(F - theta*J@U) + U; A = I - theta*dt*J;
+//   U+ = solve(A, B); hook(t+dt)
+int tf_step_theta(tf_solver* s, int32_t src, int32_t dst, double dt, double theta) {
+    TF_API_BEGIN
+    require(s, "null solver");
+    require(src != dst, "tf_step_theta: src and dst slots must differ");
+    double* U = s->st(dst);
+    tfb::d2d(U, s->st(src), (size_t)s->vecn() * sizeof(double), s->stream);
+    s->apply_dirichlet(U);
+    s->sweep(U, true);
+    s->spmv(U, s->Wjv.p, theta);                                   // (theta*J) @ U
+    const double* xs[3] = {s->F.p, s->Wjv.p, U};
+    const double cs[3] = {dt, 0, 0};
+    s->vec(TF_VEC_THETA_RHS, s->Wrhs.p, nullptr, 3, xs, cs);       // dt*(F - .) + U
+    s->factor(theta * dt);
+    s->solve(s->Wrhs.p, s->Wstage.p);
+    const double* cp[1] = {s->Wstage.p};
+    s->vec(TF_VEC_COPY, U, nullptr, 1, cp, nullptr);
+    s->apply_dirichlet(U);
+    TF_API_END
+}
+
+// Rosenbrock-Wanner fixed step, reference schemes.py:142-174.
+int tf_step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns,
+                const double* alpha, const double* gamma, const double* b,
+                const double* b_pred, int32_t hook_after, double* err_out) {
+    TF_API_BEGIN
+    require(s && alpha && gamma && b, "null argument");
+    require(ns >= 1 && ns <= 6, "tf_step_row: 1 <= s <= 6");
+    require(src != dst, "tf_step_row: src and dst slots must differ");
+    double* U = s->st(dst);
+    tfb::d2d(U, s->st(src), (size_t)s->vecn() * sizeof(double), s->stream);
+    s->apply_dirichlet(U);
+    s->sweep(U, true);                         // J(U) and F(U) = F of stage 0
+    s->factor(gamma[0] * dt);
+    const double* ks[TF_MAX_TERMS];
+    double cs[TF_MAX_TERMS];
+    for (int i = 0; i < ns; ++i) {
+        if (i > 0) {
+            for (int j = 0; j < i; ++j) { ks[j] = s->K[j].p; cs[j] = alpha[i * ns + j]; }
+            s->vec(TF_VEC_SUM, s->Wstage.p, U, i, ks, cs);         // U + sum_j alpha_ij k_j
+            s->sweep(s->Wstage.p, false);
+            for (int j = 0; j < i; ++j) cs[j] = gamma[i * ns + j];
+            s->vec(TF_VEC_SUM, s->Wsum.p, nullptr, i, ks, cs);     // sum_j gamma_ij k_j
+            s->spmv(s->Wsum.p, s->Wjv.p, 1.0);
+            const double* xs[2] = {s->F.p, s->Wjv.p};
+            const double c2[2] = {dt, dt};
+            s->vec(TF_VEC_LIN2, s->Wrhs.p, nullptr, 2, xs, c2);    // dt*F + dt*(J @ .)
+        } else {
+            const double* xs[1] = {s->F.p};
+            const double c1[1] = {dt};
+            s->vec(TF_VEC_SUM, s->Wrhs.p, nullptr, 1, xs, c1);     // dt*F
+        }
+        s->solve(s->Wrhs.p, s->K[i].p);
+    }
+    for (int j = 0; j < ns; ++j) { ks[j] = s->K[j].p; cs[j] = b[j]; }
+    s->vec(TF_VEC_SUM, U, U, ns, ks, cs);                          // U + sum_i b_i k_i
+    if (b_pred && err_out) {
+        tfb::memset0(s->red.p, sizeof(double), s->stream);
+        for (int j = 0; j < ns; ++j) cs[j] = b_pred[j];
+        s->vec(TF_VEC_MAXABS, nullptr, U, ns, ks, cs);             // ||U - (U + sum b_pred k)||_inf
+    }
+    if (hook_after) s->apply_dirichlet(U);
+    if (err_out) {
+        *err_out = 0.0;
+        if (b_pred) {
+            uint64_t bits = 0;
+            tfb::d2h(&bits, s->red.p, sizeof(bits), s->stream);
+            std::memcpy(err_out, &bits, sizeof(double));
+        }
+        s->check_status();
+    }
+    TF_API_END
+}
+
+// Linearly implicit BDF-2 (not in the reference; DESIGN.md "BDF-2"):
+//   (I - 2/3 dt J)(U+ - U) = 1/3 (U - Uprev) + 2/3 dt F     with history
+//   (I -     dt J)(U+ - U) = dt F                           first step / dt changed
+int tf_step_bdf2(tf_solver* s, int32_t src, int32_t dst, double dt) {
+    TF_API_BEGIN
+    require(s, "null solver");
+    require(src != dst, "tf_step_bdf2: src and dst slots must differ");
+    double* U = s->st(dst);
+    tfb::d2d(U, s->st(src), (size_t)s->vecn() * sizeof(double), s->stream);
+    s->apply_dirichlet(U);
+    s->sweep(U, true);
+    const bool two_step = s->bdf_have_prev &&
+        std::fabs(s->bdf_dt_prev - dt) <= 1e-12 * std::fabs(dt);
+    if (two_step) {
+        const double* xs[3] = {U, s->Uprev.p, s->F.p};
+        const double cs[3] = {1.0 / 3.0, (2.0 / 3.0) * dt, 0};
+        s->vec(TF_VEC_BDF2_RHS, s->Wrhs.p, nullptr, 3, xs, cs);
+        s->factor((2.0 / 3.0) * dt);
+    } else {
+        const double* xs[1] = {s->F.p};
+        const double c1[1] = {dt};
+        s->vec(TF_VEC_SUM, s->Wrhs.p, nullptr, 1, xs, c1);
+        s->factor(dt);
+    }
+    const double* cp[1] = {U};
+    s->vec(TF_VEC_COPY, s->Uprev.p, nullptr, 1, cp, nullptr);
+    s->bdf_have_prev = true;
+    s->bdf_dt_prev = dt;
+    s->solve(s->Wrhs.p, s->Wdel.p);
+    const double* ys[2] = {U, s->Wdel.p};
+    s->vec(TF_VEC_ADD, U, nullptr, 2, ys, nullptr);
+    s->apply_dirichlet(U);
+    TF_API_END
+}
+int tf_bdf2_reset(tf_solver* s) {
+    TF_API_BEGIN
+    require(s, "null solver");
+    s->bdf_have_prev = false;
+    TF_API_END
+}
+
+int tf_diff_norm(tf_solver* s, int32_t slot_a, int32_t slot_b, int32_t ord, double* out) {
+    TF_API_BEGIN
+    require(s && out, "null argument");
+    require(ord == 0, "tf_diff_norm: only the max norm (ord = 0) is implemented on the device");
+    // max |a - b| over everything (all variables, all systems): one scalar
+    const double* xs[2] = {s->st(slot_a), s->st(slot_b)};
+    const double cs[2] = {1.0, -1.0};
+    tfb::memset0(s->red.p, sizeof(double), s->stream);
+    s->vec(TF_VEC_MAXABS, nullptr, nullptr, 2, xs, cs);
+    uint64_t bits = 0;
+    tfb::d2h(&bits, s->red.p, sizeof(bits), s->stream);
+    std::memcpy(out, &bits, sizeof(double));
+    TF_API_END
+}
+
+int tf_sync(tf_solver* s) {
+    TF_API_BEGIN
+    require(s, "null solver");
+    tfb::stream_sync(s->stream);
+    s->check_status();
+    TF_API_END
+}
+
+// ------------------------------------------------------------- measurement
+int tf_timing_enable(tf_solver* s, int32_t on) {
+    TF_API_BEGIN
+    require(s, "null solver");
+    s->collect_timing();
+    s->timing = on != 0;
+    TF_API_END
+}
+int tf_timing_reset(tf_solver* s) {
+    TF_API_BEGIN
+    require(s, "null solver");
+    s->collect_timing();
+    for (int k = 0; k < TFK_COUNT; ++k) { s->time_ms[k] = 0; s->time_n[k] = 0; }
+    TF_API_END
+}
+int tf_timing_get(tf_solver* s, int32_t kernel, double* total_ms, int64_t* launches) {
+    TF_API_BEGIN
+    require(s, "null solver");
+    require(kernel >= 0 && kernel < TFK_COUNT, "tf_timing_get: kernel index");
+    s->collect_timing();
+    if (total_ms) *total_ms = s->time_ms[kernel];
+    if (launches) *launches = s->time_n[kernel];
+    TF_API_END
+}
+
+}  // extern "C"
