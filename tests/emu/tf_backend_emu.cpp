@@ -74,8 +74,15 @@ void launch(Module*, int kernel, unsigned gx, unsigned gy, unsigned block,
         for (int64_t t = 0; t < nthreads; ++t) tfk_chunk_body<ROWS, -1, SP, false, false>(a, (int)t); } break;
     TF_EMU_CHUNK(TFK_L1_FACTOR, TfRowsL1, true, true, false)
     TF_EMU_CHUNK(TFK_L1_SOLVE, TfRowsL1, false, false, true)
-    TF_EMU_CHUNK(TFK_BT_FACTOR, TfRowsUp, true, true, false)
-    TF_EMU_CHUNK(TFK_BT_SOLVE, TfRowsUp, false, false, true)
+    case TFK_BT_LU: { const auto& a = *(const TfLevelArgs*)args;
+        for (unsigned y = 0; y < gy; ++y) for (int64_t t = 0; t < nthreads; ++t)
+            tfk_bt_lu_body<TF_B2>(a, (int)t, y == 0 ? +1 : -1); } break;
+    case TFK_BT_SPIKE: { const auto& a = *(const TfLevelArgs*)args;
+        for (unsigned y = 0; y < gy; ++y) for (int64_t t = 0; t < nthreads; ++t)
+            tfk_bt_col_body<TF_B2>(a, (int)t, (y & 1) == 0 ? +1 : -1, (int)(y >> 1)); } break;
+    case TFK_BT_RHS: { const auto& a = *(const TfLevelArgs*)args;
+        for (unsigned y = 0; y < gy; ++y) for (int64_t t = 0; t < nthreads; ++t)
+            tfk_bt_col_body<TF_B2>(a, (int)t, y == 0 ? +1 : -1, TF_B2); } break;
 #define TF_EMU_LEVEL(ID, CALL)                                                          \
     case ID: { const auto& a = *(const TfLevelArgs*)args;                               \
         for (int64_t t = 0; t < nthreads; ++t) CALL(a, (int)t); } break;

@@ -1,0 +1,284 @@
+"""Parity checks shared by the CPU emulation suite (tests/test_emu_parity.py,
+kernel bodies executed on the host) and the GPU suite (tests/test_gpu_parity.py,
+the real HIP path through libtriflow_hip.so).  Every check compares the device
+path with the oracle / the reference's golden vectors on the same inputs."""
+import os
+from functools import partial
+
+import numpy as np
+import scipy.sparse as sps
+import scipy.sparse.linalg as spla
+
+from oracle import corpus, numpy_path as ora
+from oracle.gen_golden import HOOKS, N_FJ, STEP_CASES, step_inputs
+from triflow_amd import Model, Simulation, schemes
+from triflow_amd.compilers import hip_compiler
+from triflow_amd.device import DirichletHook
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+#: models whose expressions only use + - * / sqrt and integer powers: F and J
+#: must be bit-identical to the NumPy path.  The others call exp/... from a
+#: different libm: 4 ulp of the largest term.
+TRANSCENDENTAL = {"nonlin"}
+
+
+def device_model(name, backend, **kw):
+    eqs, dep, pars, helps = corpus.model_args(name)
+    compiler = hip_compiler if backend is None else partial(hip_compiler, backend=backend)
+    return Model(eqs, dep, pars, helps, compiler=compiler, **kw)
+
+
+def oracle_model(name, **kw):
+    eqs, dep, pars, helps = corpus.model_args(name)
+    return Model(eqs, dep, pars, helps, compiler=ora.numpy_compiler, **kw)
+
+
+# ---------------------------------------------------------------- seam #1: F / J
+def check_FJ_golden(name, backend):
+    """G1 vectors of the reference: F and the CSC Jacobian."""
+    g = np.load(os.path.join(GOLDEN, "fj_%s.npz" % name))
+    m = device_model(name, backend)
+    for periodic in (True, False):
+        for per_node in (False, True):
+            if per_node and not corpus.DEFAULT_PARS[name]:
+                continue
+            tag = "%s_%s" % ("per" if periodic else "clamp", "vec" if per_node else "sca")
+            fd = corpus.synthetic_fields(name, N_FJ, seed=3, periodic=periodic)
+            pars = corpus.synthetic_pars(name, N_FJ, periodic, per_node)
+            fields = m.fields_template(**fd)
+            F = m.F(fields, pars)
+            J = m.J(fields, pars)
+            assert isinstance(J, sps.csc_matrix)
+            assert np.array_equal(J.indptr, g[tag + "_Jindptr"])
+            assert np.array_equal(J.indices, g[tag + "_Jindices"])
+            if name in TRANSCENDENTAL:
+                assert np.allclose(F, g[tag + "_F"], rtol=1e-14, atol=1e-14 * np.abs(F).max())
+                assert np.allclose(J.data, g[tag + "_Jdata"], rtol=1e-14,
+                                   atol=1e-14 * np.abs(J.data).max())
+            else:
+                assert np.array_equal(F, g[tag + "_F"]), (name, tag)
+                # three clamped ghost columns folding onto one boundary column are
+                # summed in a different order than SciPy's COO->CSC (1 ulp)
+                d = np.abs(J.data - g[tag + "_Jdata"])
+                assert (d <= 2 * np.spacing(np.abs(g[tag + "_Jdata"]))).all(), (name, tag)
+                assert (d == 0).mean() > 0.97
+            dense = m.J(fields, pars, sparse=False)
+            assert np.array_equal(np.asarray(dense), J.toarray())
+
+
+def check_FJ_bitexact_large(name, backend, N):
+    """Against the oracle at a size with ragged chunks and several sweep segments."""
+    m, mo = device_model(name, backend), oracle_model(name)
+    for periodic in (True, False):
+        fd = corpus.synthetic_fields(name, N, seed=11, periodic=periodic, length=N * 1e-2)
+        pars = corpus.synthetic_pars(name, N, periodic)
+        F = m.F(m.fields_template(**fd), pars)
+        Fo = mo.F(mo.fields_template(**fd), pars)
+        assert np.array_equal(F, Fo)
+        J = m.J(m.fields_template(**fd), pars)
+        Jo = mo.J(mo.fields_template(**fd), pars)
+        assert abs(J - Jo).max() <= 4 * np.spacing(abs(Jo).max())
+
+
+# ---------------------------------------------------------------- seam #3: solver
+def bound_solver(m, fd, pars, **opts):
+    cm = m._device
+    N = fd["x"].size
+    solver = cm.solver(N, pars["periodic"], 1, 0, **opts)
+    cm.bind_inputs(solver, fd["x"], [pars[k] for k in cm.pars],
+                   [fd[k] for k in m._help_funcs] if cm.nh else None)
+    solver.set_state(0, np.array([fd[k] for k in m._dep_vars]))
+    return solver
+
+
+def check_linear_solve(name, backend, N, level_opts, c=0.01, tol=1e-9):
+    """(I - cJ) x = b against SuperLU (the reference's solver, schemes.py:149,557)
+    for every level plan in ``level_opts``, periodic and clamped."""
+    m, mo = device_model(name, backend), oracle_model(name)
+    rng = np.random.default_rng(5)
+    for periodic in (True, False):
+        fd = corpus.synthetic_fields(name, N, seed=7, periodic=periodic, length=N * 5e-3)
+        pars = corpus.synthetic_pars(name, N, periodic)
+        Jo = mo.J(mo.fields_template(**fd), pars)
+        n = N * m._nvar
+        A = sps.identity(n, format="csc") - c * Jo
+        rhs = rng.standard_normal(n)
+        xs = spla.spsolve(A, rhs)
+        for opts in level_opts:
+            solver = bound_solver(m, fd, pars, **opts)
+            solver.eval(0, with_j=True)
+            solver.factor(c)
+            x = solver.solve(rhs)[0]
+            err = np.abs(x - xs).max() / np.abs(xs).max()
+            assert err <= tol, (name, periodic, opts, solver.describe(), err)
+            y = solver.matvec(rhs)[0]
+            assert np.abs(y - Jo @ rhs).max() <= 1e-12 * max(1.0, np.abs(Jo @ rhs).max())
+
+
+# ---------------------------------------------------------------- seam #2: schemes
+DEVICE_SCHEMES = {
+    "Theta1": lambda m: schemes.Theta(m, theta=1),
+    "Theta05": lambda m: schemes.Theta(m, theta=0.5),
+    "Theta0": lambda m: schemes.Theta(m, theta=0),
+    "ROS2": lambda m: schemes.ROS2(m),
+    "ROS3PRw": lambda m: schemes.ROS3PRw(m, time_stepping=False),
+    "ROS3PRL": lambda m: schemes.ROS3PRL(m, time_stepping=False),
+    "RODASPR": lambda m: schemes.RODASPR(m, time_stepping=False),
+    "ROS3PRw_adapt": lambda m: schemes.ROS3PRw(m, tol=1e-1),
+    "ROS3PRL_adapt": lambda m: schemes.ROS3PRL(m, tol=1e-1),
+    "RODASPR_adapt": lambda m: schemes.RODASPR(m, tol=1e-1),
+}
+#: per-case relative tolerance on U after each of the five steps.  The solver is
+#: not SuperLU, so agreement is bounded by cond(A) * eps of BOTH solvers: the
+#: film model at the benchmark dx has cond ~ 1e10 (DESIGN.md "tolerances").
+STEP_TOL = {"cfg1": 1e-11, "cfg1_nohook": 1e-11, "diff_per": 1e-11, "burgers_per": 1e-11,
+            "film_per": 2e-7, "film_clamp": 2e-7, "stiff_clamp": 1e-9}
+DEVICE_HOOKS = {"cfg1": DirichletHook(U={0: 1.0, -1: 0.0}),
+                "cfg5": DirichletHook(A={0: 1.0, -1: 1.0}), None: None}
+
+
+def check_steps_golden(case, backend, python_hook=False, only=None):
+    """G2: five steps of every scheme against the reference's trajectory."""
+    g = np.load(os.path.join(GOLDEN, "steps.npz"))
+    cname, mname, N, periodic, dt, hook = case
+    m = device_model(mname, backend)
+    fdict, pars = step_inputs(case)
+    tol = STEP_TOL[cname]
+    for sname, make in DEVICE_SCHEMES.items():
+        key = "%s|%s" % (cname, sname)
+        if key not in g.files or (only and sname not in only):
+            continue
+        scheme = make(m)
+        fields = m.fields_template(**fdict)
+        t = 0.0
+        kw = {}
+        if hook:
+            kw["hook"] = HOOKS[hook] if python_hook else DEVICE_HOOKS[hook]
+        with np.errstate(all="ignore"):
+            for k in range(5):
+                t, fields = scheme(t, fields, dt, pars, **kw)
+                ref = g[key][k]
+                err = np.abs(fields.uflat - ref).max() / np.abs(ref).max()
+                assert err <= tol, (key, k, err)
+        assert np.isclose(t, 5 * dt)
+
+
+def check_bdf2(backend):
+    """BDF-2 (not in the reference): device scheme against the oracle's
+    restatement, same F/J, SuperLU vs banded solver."""
+    for mname, N, periodic, dt, hook in (("M2_diff", 40, True, 1e-2, None),
+                                         ("M5_stiff", 24, False, 1e-3, "cfg5")):
+        m, mo = device_model(mname, backend), oracle_model(mname)
+        if mname == "M5_stiff":
+            _, fd, pars, _, _ = corpus.config_inputs(5, N)
+        else:
+            fd = corpus.synthetic_fields(mname, N, seed=2, periodic=periodic)
+            pars = corpus.synthetic_pars(mname, N, periodic)
+        s_dev, s_ora = schemes.BDF2(m), ora.BDF2(mo)
+        f_dev, f_ora = m.fields_template(**fd), mo.fields_template(**fd)
+        t = 0.0
+        for k in range(6):
+            kw_d = dict(hook=DEVICE_HOOKS[hook]) if hook else {}
+            kw_o = dict(hook=HOOKS[hook]) if hook else {}
+            _, f_dev = s_dev(t, f_dev, dt, pars, **kw_d)
+            t, f_ora = s_ora(t, f_ora, dt, pars, **kw_o)
+            err = np.abs(f_dev.uflat - f_ora.uflat).max() / np.abs(f_ora.uflat).max()
+            assert err <= 1e-10, (mname, k, err)
+
+
+def check_simulation_golden(backend):
+    """G3: Simulation on config 1, device Theta scheme, python and declarative hook,
+    with and without the default step-doubling wrapper."""
+    g = np.load(os.path.join(GOLDEN, "simulation.npz"))
+    for ts in (False, True):
+        for hook in (corpus.dirichlet_hook_cfg1, DEVICE_HOOKS["cfg1"]):
+            m = device_model("M1_advdiff", backend)
+            _, fdict, pars, dt, _ = corpus.config_inputs(1, 200)
+            sim = Simulation(m, fdict, pars, dt, hook=hook, tmax=2.5, scheme=schemes.Theta,
+                             time_stepping=ts)
+            us, tl = [], []
+            for t, fields in sim:
+                tl.append(t)
+                us.append(fields.uflat.copy())
+            assert np.allclose(tl, g["Theta_ts%i_t" % ts], rtol=0, atol=1e-12)
+            assert np.abs(np.array(us) - g["Theta_ts%i_U" % ts]).max() <= 1e-10, (ts, hook)
+
+
+def check_resident_fields(backend):
+    """Device-backed containers: no upload when handed back untouched, snapshots
+    stay valid while newer steps recycle the slots, inputs are never mutated."""
+    m = device_model("M2_diff", backend)
+    fd = corpus.synthetic_fields("M2_diff", 64, seed=1)
+    pars = corpus.synthetic_pars("M2_diff", 64, True)
+    scheme = schemes.Theta(m)
+    f0 = m.fields_template(**fd)
+    u0 = f0.uflat.copy()
+    t, f1 = scheme(0.0, f0, 1e-2, pars)
+    assert f1._device_backing() is not None
+    assert np.array_equal(f0.uflat, u0)
+    snaps = [f1]
+    f = f1
+    for _ in range(7):
+        t, f = scheme(t, f, 1e-2, pars)
+        snaps.append(f)
+    stepper = f._device_backing().stepper
+    assert stepper.nstate < len(snaps)
+    # replay on the host copies: identical trajectories
+    g = m.fields_template(**fd)
+    for k in range(8):
+        _, g = scheme(0.0, g, 1e-2, pars)
+        g["U"]                                   # force the host copy each step
+        assert np.array_equal(np.asarray(snaps[k]["U"]), np.asarray(g["U"])), k
+    c = snaps[-1].copy()
+    assert np.array_equal(np.asarray(c["U"]), np.asarray(snaps[-1]["U"]))
+
+
+def check_errors(backend):
+    """Error behaviour of the reference seams: KeyError for a missing parameter
+    (routines.py:11,40), RuntimeError from the step control (schemes.py:229-238)."""
+    import pytest
+    m = device_model("M2_diff", backend)
+    x = np.linspace(0, 10, 50, endpoint=False)
+    fields = m.fields_template(x=x, U=np.cos(x * 2 * np.pi / 10))
+    with pytest.raises(KeyError):
+        m.F(fields, dict(periodic=True))
+    with pytest.raises(KeyError):
+        schemes.Theta(m)(0, fields, 1.0, dict(k=1.0))
+    pars = dict(periodic=True, k=1)
+    sim = Simulation(m, fields, pars, dt=1, tol=1e-1, max_iter=2)
+    with pytest.raises(RuntimeError):
+        for _ in sim:
+            pass
+    assert sim.status == "failed"
+    sim = Simulation(m, fields, pars, dt=1, tol=1e-1, dt_min=.1)
+    with pytest.raises(RuntimeError):
+        for _ in sim:
+            pass
+
+
+def check_heat_steady_state(backend, scheme_cls, dirichlet):
+    """The reference's own integration tests (tests/test_simulation.py:20-58)."""
+    m = device_model("M2_diff", backend)
+    x = np.linspace(0, 10, 50, endpoint=False)
+    fields = m.fields_template(x=x, U=np.cos(x * 2 * np.pi / 10))
+    if dirichlet:
+        def hook(t, fields, parameters):
+            fields["U"][0] = 1
+            fields["U"][-1] = 1
+            return fields, parameters
+        sim = Simulation(m, fields, dict(periodic=False, k=1), hook=hook, scheme=scheme_cls,
+                         dt=.1 if not isinstance(dirichlet, float) else dirichlet,
+                         tmax=100 if dirichlet is True else 20, tol=1e-1)
+        for t, f in sim:
+            pass
+        assert np.isclose(t, sim.tmax)
+        if dirichlet is True:
+            assert np.isclose(np.asarray(f["U"]), 1, atol=1e-1).all()
+    else:
+        sim = Simulation(m, fields, dict(periodic=True, k=1), scheme=scheme_cls, dt=1,
+                         tmax=100, tol=1e-1)
+        for t, f in sim:
+            pass
+        assert t == 100
+        assert np.isclose(np.asarray(f["U"]).mean(), 0)

@@ -1,0 +1,69 @@
+"""CPU suite: the kernel bodies of csrc/tf_kernels.h and the whole host stack
+(runtime C ABI, ctypes binding, compiler plugin, schemes, Simulation) executed
+through the test-only host emulation (tests/emu) and compared with the oracle
+and the reference's golden vectors.  The GPU suite (test_gpu_parity.py) runs
+the same checks through the real HIP path."""
+import pytest
+
+from oracle.gen_golden import STEP_CASES
+from tests import parity_cases as pc
+from tests.emu.build_emu import EmuBackend
+from triflow_amd import schemes
+
+
+@pytest.fixture(scope="module")
+def backend():
+    return EmuBackend()
+
+
+FJ_MODELS = ["M1_advdiff", "M2_diff", "bivar", "helper_d", "upwind3_par", "upwind2_state",
+             "kuramoto", "wave", "nonlin", "M3_film", "M5_stiff"]
+
+
+@pytest.mark.parametrize("name", FJ_MODELS)
+def test_FJ_golden(name, backend):
+    pc.check_FJ_golden(name, backend)
+
+
+@pytest.mark.parametrize("name,N", [("M3_film", 301), ("M1_advdiff", 1000)])
+def test_FJ_ragged_chunks(name, N, backend):
+    pc.check_FJ_bitexact_large(name, backend, N)
+
+
+@pytest.mark.parametrize("name", ["M2_diff", "M3_film", "M5_stiff", "kuramoto"])
+def test_linear_solve(name, backend):
+    plans = [dict(m1=4, m_upper=2), dict(m1=7, m_upper=3), dict(m1=32, m_upper=8),
+             dict(m1=10 ** 6)]
+    pc.check_linear_solve(name, backend, 203, plans, tol=1e-9)
+
+
+@pytest.mark.parametrize("case", [c for c in pc.STEP_CASES if c[0] in
+                                  ("cfg1", "film_per", "stiff_clamp")],
+                         ids=lambda c: c[0])
+def test_steps_golden(case, backend):
+    pc.check_steps_golden(case, backend)
+
+
+def test_steps_golden_python_hook(backend):
+    pc.check_steps_golden(STEP_CASES[0], backend, python_hook=True,
+                          only=("Theta1", "ROS2", "RODASPR_adapt"))
+
+
+def test_bdf2(backend):
+    pc.check_bdf2(backend)
+
+
+def test_simulation_golden(backend):
+    pc.check_simulation_golden(backend)
+
+
+def test_resident_fields(backend):
+    pc.check_resident_fields(backend)
+
+
+def test_errors(backend):
+    pc.check_errors(backend)
+
+
+def test_heat_steady_state(backend):
+    pc.check_heat_steady_state(backend, schemes.RODASPR, dirichlet=False)

@@ -1,0 +1,163 @@
+"""GPU suite (-m gpu): the real HIP path through libtriflow_hip.so on an
+MI355X, against the oracle and the reference's golden vectors, plus
+size-independent properties at the BASELINE sizes."""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+import scipy.sparse.linalg as spla
+
+from oracle import corpus
+from oracle.gen_golden import STEP_CASES
+from tests import parity_cases as pc
+from triflow_amd import schemes
+from triflow_amd.tableaux import TABLEAUX
+
+pytestmark = pytest.mark.gpu
+HIP = None      # default back end: hipcc + libtriflow_hip.so
+
+
+def test_native_library_is_the_one_running():
+    from triflow_amd import compilers
+    lib = compilers.HipBackend().library()
+    is_device, ndev = lib.runtime_info()
+    assert is_device and ndev >= 1
+    assert lib.path.endswith("triflow_amd/lib/libtriflow_hip.so")
+
+
+@pytest.mark.parametrize("name", sorted(corpus.MODELS))
+def test_FJ_golden(name):
+    pc.check_FJ_golden(name, HIP)
+
+
+@pytest.mark.parametrize("name,N", [("M3_film", 30011), ("M1_advdiff", 100003),
+                                    ("M5_stiff", 20001)])
+def test_FJ_bitexact_ragged(name, N):
+    pc.check_FJ_bitexact_large(name, HIP, N)
+
+
+@pytest.mark.parametrize("name", ["M2_diff", "M1_advdiff", "M3_film", "M5_stiff", "kuramoto",
+                                  "kdv", "wave", "upwind2_par"])
+def test_linear_solve_small(name):
+    plans = [dict(m1=4, m_upper=2), dict(m1=7, m_upper=3), dict(m1=32, m_upper=8),
+             dict(m1=10 ** 6), dict()]
+    pc.check_linear_solve(name, HIP, 203, plans, tol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["M2_diff", "M3_film", "M5_stiff"])
+def test_linear_solve_medium(name):
+    pc.check_linear_solve(name, HIP, 20011, [dict(), dict(m1=16, m_upper=4)], tol=1e-8)
+
+
+@pytest.mark.parametrize("case", STEP_CASES, ids=lambda c: c[0])
+def test_steps_golden(case):
+    pc.check_steps_golden(case, HIP)
+
+
+@pytest.mark.parametrize("case", [STEP_CASES[0], STEP_CASES[5]], ids=lambda c: c[0])
+def test_steps_golden_python_hook(case):
+    pc.check_steps_golden(case, HIP, python_hook=True,
+                          only=("Theta1", "ROS2", "RODASPR", "ROS3PRw_adapt"))
+
+
+def test_bdf2():
+    pc.check_bdf2(HIP)
+
+
+def test_simulation_golden():
+    pc.check_simulation_golden(HIP)
+
+
+def test_resident_fields():
+    pc.check_resident_fields(HIP)
+
+
+def test_errors():
+    pc.check_errors(HIP)
+
+
+@pytest.mark.parametrize("scheme", [schemes.ROS2, schemes.ROS3PRL, schemes.ROS3PRw,
+                                    schemes.RODASPR, schemes.Theta, schemes.BDF2])
+def test_heat_steady_state(scheme):
+    pc.check_heat_steady_state(HIP, scheme, dirichlet=False)
+
+
+@pytest.mark.parametrize("scheme", [schemes.ROS3PRL, schemes.ROS3PRw, schemes.RODASPR])
+def test_heat_dirichlet(scheme):
+    pc.check_heat_steady_state(HIP, scheme, dirichlet=True)
+
+
+# ---- BASELINE sizes: properties that do not need the (slow) oracle at 1e6 ----
+def _cfg_solver(cfg, N=None, **opts):
+    name, fd, pars, dt, sch = corpus.config_inputs(cfg, N)
+    m = pc.device_model(name, HIP)
+    solver = pc.bound_solver(m, fd, pars, **opts)
+    return m, solver, fd, pars, dt
+
+
+@pytest.mark.parametrize("cfg,gamma", [(2, 1.0), (3, TABLEAUX["ROS2"].gamma[0, 0]), (5, 2. / 3.)])
+def test_full_size_solver_residual(cfg, gamma):
+    """(I - cJ) x = b at the BASELINE size: the residual computed on the host
+    with the downloaded Jacobian must be at rounding level, and solving with
+    A @ x_known must give x_known back (round trip)."""
+    m, solver, fd, pars, dt = _cfg_solver(cfg)
+    N, nvar = fd["x"].size, m._nvar
+    solver.eval(0, with_j=True)
+    J = m._device.pattern(N, pars["periodic"]).assemble(solver.get_J()[0])
+    c = gamma * dt
+    A = sps.identity(N * nvar, format="csr") - c * J.tocsr()
+    rng = np.random.default_rng(0)
+    x_known = rng.standard_normal(N * nvar)
+    b = A @ x_known
+    solver.factor(c)
+    x = solver.solve(b)[0]
+    r = np.abs(A @ x - b).max() / np.abs(b).max()
+    assert r <= 1e-9, r
+    # forward error bounded by cond * eps: a loose, size-independent sanity bound
+    assert np.abs(x - x_known).max() <= 1e-4 * np.abs(x_known).max()
+    y = solver.matvec(x_known)[0]
+    assert np.abs(y - J @ x_known).max() <= 1e-11 * np.abs(J @ x_known).max()
+    solver.close()
+
+
+def test_full_size_sweep_matches_subsampled_oracle():
+    """F at N = 1e6 (config 3): every 9973-th window recomputed by the oracle on
+    the extracted neighbourhood must agree bit for bit (F is local)."""
+    name, fd, pars, dt, _ = corpus.config_inputs(3)
+    m = pc.device_model(name, HIP)
+    mo = pc.oracle_model(name)
+    N = fd["x"].size
+    F = m.F(m.fields_template(**fd), pars).reshape(N, 3)
+    dx = (fd["x"][-1] - fd["x"][0]) / (N - 1)
+    for g in range(5, N - 5, 9973):
+        sl = slice(g - 2, g + 3)
+        sub = {k: v[sl] for k, v in fd.items()}
+        sub["x"] = np.arange(5) * dx            # same dx to the last bit is not
+        sub_pars = dict(pars, periodic=False)   # guaranteed: compare through dx
+        fo = mo.fields_template(**sub)
+        # evaluate the oracle's lambdified F directly on the centre node
+        env, _, _, _ = __import__("oracle.numpy_path", fromlist=["x"]).stencil_views(
+            mo, sub["x"], *[sub[k] for k in mo._dep_vars], *[sub_pars[k] for k in mo._pars],
+            False)
+        env["dx"] = dx
+        from sympy import lambdify
+        from oracle.numpy_path import _lambdify_modules
+        f_func = lambdify(mo._symbolic_args, mo.F_array.tolist(), modules=_lambdify_modules())
+        vals = f_func(*[env[k] for k in mo._args])
+        centre = np.array([np.broadcast_to(v, (5,))[2] for v in vals])
+        assert np.array_equal(F[g], centre), g
+
+
+@pytest.mark.parametrize("cfg", [2, 3])
+def test_full_size_step_properties(cfg):
+    """One implicit step at N = 1e6: finite, and the periodic models conserve
+    the mean of their conservative variable to rounding (dU/dt is a divergence)."""
+    name, fd, pars, dt, sch = corpus.config_inputs(cfg)
+    m = pc.device_model(name, HIP)
+    fields = m.fields_template(**fd)
+    scheme = schemes.Theta(m) if sch == "Theta" else schemes.ROS2(m)
+    t, new = scheme(0.0, fields, dt, pars)
+    key = "U" if cfg == 2 else "h"
+    before, after = np.asarray(fields[key]), np.asarray(new[key])
+    assert np.isfinite(after).all()
+    assert abs(after.mean() - before.mean()) <= 1e-11 * max(1.0, abs(before).max())
+    assert not np.array_equal(before, after)

@@ -272,7 +272,7 @@ class DeviceSolver:
         self.lib.call("tf_step_row", self.handle, src, dst, float(dt), s, _dptr(alpha),
                       _dptr(gamma), _dptr(b), _dptr(bp) if bp is not None else None,
                       int(hook_after), C.byref(err) if want_err else None)
-        return err.value if (want_err and bp is not None) else None
+        return np.float64(err.value) if (want_err and bp is not None) else None
 
     def step_bdf2(self, src, dst, dt):
         self.lib.call("tf_step_bdf2", self.handle, src, dst, float(dt))

@@ -39,7 +39,8 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "lib", "libtriflow_hip.so")
 CACHE_DIR = os.path.join(PKG_DIR, "_cache")
 GPU_ARCH = "gfx950"
-HIPCC_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=" + GPU_ARCH]
+HIPCC_FLAGS = [*os.environ.get("TRIFLOW_HIPCC_OPT", "-O3").split(), "-std=c++17",
+               "-ffp-contract=off", "--offload-arch=" + GPU_ARCH]
 
 _SKELETON = ("tf_args.h", "tf_math.h", "tf_kernels.h", "tf_entry_hip.h")
 _TU_HEAD = ('#include <hip/hip_runtime.h>\n'

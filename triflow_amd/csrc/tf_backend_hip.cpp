@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -65,6 +67,24 @@ Module* module_load(const void* image, size_t) {
             delete m;
             throw std::runtime_error(std::string("kernel missing from code object: ") + names[k]);
         }
+    }
+    // Debug aid for compiler bisection: TF_ALT_HSACO=<file> TF_ALT_MASK=<bits> takes
+    // the kernels whose bit is set from a second build of the same model.
+    if (const char* alt = getenv("TF_ALT_HSACO")) {
+        const char* mask_s = getenv("TF_ALT_MASK");
+        unsigned long mask = mask_s ? strtoul(mask_s, nullptr, 0) : 0;
+        FILE* f = fopen(alt, "rb");
+        if (f && mask) {
+            fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+            std::string img(n, '\0');
+            if (fread(&img[0], 1, n, f) == (size_t)n) {
+                hipModule_t am;
+                if (hipModuleLoadData(&am, img.data()) == hipSuccess)
+                    for (int k = 0; k < TFK_COUNT; ++k)
+                        if ((mask >> k) & 1ul) (void)hipModuleGetFunction(&m->fn[k], am, names[k]);
+            }
+        }
+        if (f) fclose(f);
     }
     return m;
 }

@@ -74,13 +74,15 @@ __global__ void __launch_bounds__(64) tfk_l1_backsub(TfLevelArgs a) { tfk_backsu
 
 // ---- banded solver, levels >= 2 (explicit block-tridiagonal rows) -----------
 typedef TfRowsBT<TF_B2> TfRowsUp;
-__global__ void __launch_bounds__(64) tfk_bt_factor(TfLevelArgs a) {
-    if (blockIdx.y == 0) tfk_chunk_body<TfRowsUp, +1, true, true, false>(a, TF_GID);
-    else tfk_chunk_body<TfRowsUp, -1, true, false, false>(a, TF_GID);
+// grid.y: 0 = walk down, 1 = walk up; tfk_bt_spike: grid.y = 2 * b (direction, column)
+__global__ void __launch_bounds__(64) tfk_bt_lu(TfLevelArgs a) {
+    tfk_bt_lu_body<TF_B2>(a, TF_GID, blockIdx.y == 0 ? +1 : -1);
 }
-__global__ void __launch_bounds__(64) tfk_bt_solve(TfLevelArgs a) {
-    if (blockIdx.y == 0) tfk_chunk_body<TfRowsUp, +1, false, false, true>(a, TF_GID);
-    else tfk_chunk_body<TfRowsUp, -1, false, false, false>(a, TF_GID);
+__global__ void __launch_bounds__(64) tfk_bt_spike(TfLevelArgs a) {
+    tfk_bt_col_body<TF_B2>(a, TF_GID, (blockIdx.y & 1) == 0 ? +1 : -1, blockIdx.y >> 1);
+}
+__global__ void __launch_bounds__(64) tfk_bt_rhs(TfLevelArgs a) {
+    tfk_bt_col_body<TF_B2>(a, TF_GID, blockIdx.y == 0 ? +1 : -1, TF_B2);
 }
 __global__ void __launch_bounds__(64) tfk_bt_asm_mat(TfLevelArgs a) { tfk_asm_body<TfRowsUp, true>(a, TF_GID); }
 __global__ void __launch_bounds__(64) tfk_bt_asm_rhs(TfLevelArgs a) { tfk_asm_body<TfRowsUp, false>(a, TF_GID); }

@@ -282,6 +282,7 @@ TF_DEVICE void tfk_dirichlet_elem(const TfDirichletArgs& a, int t) {
 //            stored normalised U rows.
 
 template <int B> struct TfBlk { double v[B][B]; };
+template <int V> struct TfInt { static constexpr int value = V; };
 
 template <int B>
 TF_DEVICE void tf_blk_zero(double (&a)[B][B]) {
@@ -558,19 +559,27 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
 #pragma unroll
     for (int q = 0; q < MP; ++q) fetch(q, q);
 
-    for (int j = 0; j < mI; ++j) {
-        fetch(MP, j + MP);
-        double Dinv[B][B];
-        ok = tf_blk_inverse<B>(R[0][0], Dinv) && ok;
+    // one pivot; HIST >= 0 also records the normalised row as tip history slot HIST
+    // (only the last MP pivots are recorded, in a peeled epilogue, so that the
+    // history is not carried through the main loop)
+    auto pivot = [&](int j, auto hist_tag) {
+        constexpr int HIST = decltype(hist_tag)::value;
+        // normalise the pivot row first, fetch the incoming row afterwards: the
+        // B x B temporaries of the inverse and the new row are never live together
         double Un[MP][B][B], yn[B];
         double En[SPIKE ? MP : 1][B][B];
+        {
+            double Dinv[B][B];
+            ok = tf_blk_inverse<B>(R[0][0], Dinv) && ok;
 #pragma unroll
-        for (int c = 1; c <= MP; ++c) tf_mm<B>(Un[c - 1], Dinv, R[0][c]);
-        tf_mv<B>(yn, Dinv, y[0]);
-        if (SPIKE) {
+            for (int c = 1; c <= MP; ++c) tf_mm<B>(Un[c - 1], Dinv, R[0][c]);
+            tf_mv<B>(yn, Dinv, y[0]);
+            if (SPIKE) {
 #pragma unroll
-            for (int t = 0; t < MP; ++t) tf_mm<B>(En[t], Dinv, Es[0][t]);
+                for (int t = 0; t < MP; ++t) tf_mm<B>(En[t], Dinv, Es[0][t]);
+            }
         }
+        fetch(MP, j + MP);
 #pragma unroll
         for (int q = 1; q <= MP; ++q) {
 #pragma unroll
@@ -599,25 +608,16 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
                 for (int r = 0; r < B; ++r) a.yt[(int64_t)r * L.plane + s] = yn[r];
             }
         }
-        // history of the last MP pivots (slot MP-1 = newest)
+        if (HIST >= 0) {
+            constexpr int H = HIST >= 0 ? HIST : 0;
 #pragma unroll
-        for (int h = 0; h < MP - 1; ++h) {
+            for (int c = 0; c < MP; ++c) tf_blk_copy<B>(Uh[H][c], Un[c]);
 #pragma unroll
-            for (int c = 0; c < MP; ++c) tf_blk_copy<B>(Uh[h][c], Uh[h + 1][c]);
-#pragma unroll
-            for (int r = 0; r < B; ++r) yh[h][r] = yh[h + 1][r];
+            for (int r = 0; r < B; ++r) yh[H][r] = yn[r];
             if (SPIKE) {
 #pragma unroll
-                for (int t = 0; t < MP; ++t) tf_blk_copy<B>(Eh[SPIKE ? h : 0][SPIKE ? t : 0], Eh[SPIKE ? h + 1 : 0][SPIKE ? t : 0]);
+                for (int t = 0; t < MP; ++t) tf_blk_copy<B>(Eh[SPIKE ? H : 0][SPIKE ? t : 0], En[SPIKE ? t : 0]);
             }
-        }
-#pragma unroll
-        for (int c = 0; c < MP; ++c) tf_blk_copy<B>(Uh[MP - 1][c], Un[c]);
-#pragma unroll
-        for (int r = 0; r < B; ++r) yh[MP - 1][r] = yn[r];
-        if (SPIKE) {
-#pragma unroll
-            for (int t = 0; t < MP; ++t) tf_blk_copy<B>(Eh[SPIKE ? MP - 1 : 0][SPIKE ? t : 0], En[SPIKE ? t : 0]);
         }
         // slide the window
 #pragma unroll
@@ -632,7 +632,11 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
                 for (int t = 0; t < MP; ++t) tf_blk_copy<B>(Es[SPIKE ? q : 0][SPIKE ? t : 0], Es[SPIKE ? q + 1 : 0][SPIKE ? t : 0]);
             }
         }
-    }
+    };
+    for (int j = 0; j < mI - MP; ++j) pivot(j, TfInt<-1>());
+    pivot(mI - MP, TfInt<0>());
+    if (MP > 1) pivot(mI - MP + 1, TfInt<(MP > 1 ? 1 : 0)>());
+    static_assert(MP <= 2, "tip epilogue is written for MP <= 2");
 
     // ---- tips: back-substitute the last MP pivots (local k = 0..MP-1 <-> local
     // node mI-MP+k); unknowns beyond the interior are the separator ahead.
@@ -698,6 +702,123 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
         }
     }
     if (!ok) *a.status = 1;
+}
+
+// ---- levels >= 2: block-tridiagonal chunks with stored factors --------------
+// The reduced systems are small (P1 nodes of b x b blocks) but their blocks are
+// big (b = MP*nvar), so here the factors ARE stored and the work is split into
+//   tfk_bt_lu   one thread per (chunk, direction): block LU of the interior,
+//               keeps Dinv_j and the normalised ahead block Un_j = Dinv_j * A(j, j+1)
+//   tfk_bt_col  one thread per (chunk, direction, column): forward elimination
+//               of ONE right-hand side through the stored factors -- a column of
+//               the spike (factor phase) or the actual rhs (solve phase)
+// which keeps every thread at a few b-vectors of registers.
+template <int BB>
+TF_DEVICE void tfk_bt_lu_body(const TfLevelArgs& a, int pg, int dir) {
+    typedef TfTips<BB, 1> Tip;
+    const TfLayout& L = a.L;
+    if (pg >= L.Ptot) return;
+    TfRowsBT<BB> rows(a, pg);
+    const int mI = rows.len - 1;
+    const int di = dir > 0 ? 0 : 1;
+    bool ok = true;
+    double S[BB][BB], Un[BB][BB];
+    for (int j = 0; j < mI; ++j) {
+        const int i = dir > 0 ? j : mI - 1 - j;
+        const int64_t s = tf_idx(L, pg, i);
+        double row[3][BB][BB];
+        rows.load(i, row);
+        if (j == 0) tf_blk_copy<BB>(S, row[1]);
+        else {                                       // S = dia - behind * Un_prev
+            tf_blk_copy<BB>(S, row[1]);
+            tf_mm_sub<BB>(S, row[dir > 0 ? 0 : 2], Un);
+        }
+        double Dinv[BB][BB];
+        ok = tf_blk_inverse<BB>(S, Dinv) && ok;
+        tf_mm<BB>(Un, Dinv, row[dir > 0 ? 2 : 0]);
+        double* Uout = dir > 0 ? a.Ut : a.Unup;
+#pragma unroll
+        for (int r = 0; r < BB; ++r)
+#pragma unroll
+            for (int c = 0; c < BB; ++c) {
+                a.Dinv[(int64_t)((di * BB + r) * BB + c) * L.plane + s] = Dinv[r][c];
+                Uout[(int64_t)(r * BB + c) * L.plane + s] = Un[r][c];
+            }
+    }
+    // response of the last pivot to the separator ahead
+    double* tips = dir > 0 ? a.tips_dn : a.tips_up;
+#pragma unroll
+    for (int r = 0; r < BB; ++r)
+#pragma unroll
+        for (int c = 0; c < BB; ++c)
+            tips[(int64_t)(dir > 0 ? Tip::W(0, 0, r, c) : Tip::V(0, 0, r, c)) * L.Ptot + pg] = Un[r][c];
+    if (!ok) *a.status = 1;
+}
+
+// col < BB: spike column `col` (factor phase); col == BB: the right-hand side
+template <int BB>
+TF_DEVICE void tfk_bt_col_body(const TfLevelArgs& a, int pg, int dir, int col) {
+    typedef TfTips<BB, 1> Tip;
+    const TfLayout& L = a.L;
+    if (pg >= L.Ptot) return;
+    const int e = pg / L.P, p = pg - e * L.P;
+    const int len = tf_len(L, p), mI = len - 1, start = tf_start(L, p);
+    const int di = dir > 0 ? 0 : 1;
+    const bool is_rhs = col >= BB;
+    const int behind = dir > 0 ? 0 : 2;              // block of a row that couples backwards
+    double ev[BB], en[BB];
+#pragma unroll
+    for (int r = 0; r < BB; ++r) { ev[r] = 0.0; en[r] = 0.0; }
+    for (int j = 0; j < mI; ++j) {
+        const int i = dir > 0 ? j : mI - 1 - j;
+        const int64_t s = tf_idx(L, pg, i);
+        const int g = start + i;
+        // the backward coupling of this row (absent at a non-periodic system end)
+        const bool has_behind = L.periodic || (dir > 0 ? g > 0 : g < L.N - 1);
+        if (j == 0) {
+            if (is_rhs) {
+#pragma unroll
+                for (int r = 0; r < BB; ++r) ev[r] = a.rhs[(int64_t)r * L.plane + s];
+            } else {
+#pragma unroll
+                for (int r = 0; r < BB; ++r)
+                    ev[r] = has_behind ? a.Ablk[(int64_t)((behind * BB + r) * BB + col) * L.plane + s] : 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < BB; ++r) {
+                double acc = is_rhs ? a.rhs[(int64_t)r * L.plane + s] : 0.0;
+#pragma unroll
+                for (int k = 0; k < BB; ++k)
+                    acc = tf_fma(-a.Ablk[(int64_t)((behind * BB + r) * BB + k) * L.plane + s], en[k], acc);
+                ev[r] = acc;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < BB; ++r) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < BB; ++k)
+                acc = tf_fma(a.Dinv[(int64_t)((di * BB + r) * BB + k) * L.plane + s], ev[k], acc);
+            en[r] = acc;
+        }
+        if (dir > 0) {
+            if (is_rhs) {
+#pragma unroll
+                for (int r = 0; r < BB; ++r) a.yt[(int64_t)r * L.plane + s] = en[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < BB; ++r) a.Et[(int64_t)(r * BB + col) * L.plane + s] = en[r];
+            }
+        }
+    }
+    double* tips = dir > 0 ? a.tips_dn : a.tips_up;
+#pragma unroll
+    for (int r = 0; r < BB; ++r) {
+        const int slot = is_rhs ? Tip::y(0, r)
+                                : (dir > 0 ? Tip::V(0, 0, r, col) : Tip::W(0, 0, r, col));
+        tips[(int64_t)slot * L.Ptot + pg] = en[r];
+    }
 }
 
 // ---- interface (separator) equations -> next level --------------------------

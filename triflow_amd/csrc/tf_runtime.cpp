@@ -66,7 +66,7 @@ struct DevBuf {
 struct Level {
     TfLayout L;
     int B = 0, MP = 0;
-    DevBuf Ablk, rhs, x, Ut, Et, yt, tips_dn, tips_up;
+    DevBuf Ablk, rhs, x, Ut, Et, yt, tips_dn, tips_up, Dinv, Unup;
 };
 
 }  // namespace
@@ -244,7 +244,7 @@ struct tf_solver {
         a.L = lv.L; a.Jv = Jv.p; a.c = factor_c; a.Ablk = lv.Ablk.p;
         a.rhs = l == 0 ? rhs1 : lv.rhs.p;
         a.x = l == 0 ? x1 : lv.x.p;
-        a.Ut = lv.Ut.p; a.Et = lv.Et.p; a.yt = lv.yt.p;
+        a.Ut = lv.Ut.p; a.Et = lv.Et.p; a.yt = lv.yt.p; a.Dinv = lv.Dinv.p; a.Unup = lv.Unup.p;
         a.tips_dn = lv.tips_dn.p; a.tips_up = lv.tips_up.p;
         a.Lnext = nx.L; a.Anext = nx.Ablk.p; a.rhsnext = nx.rhs.p; a.xnext = nx.x.p;
         a.status = status;
@@ -257,7 +257,11 @@ struct tf_solver {
             TfLevelArgs a = level_args(l, nullptr, nullptr);
             a.rhs = nullptr;
             unsigned gx = cdiv(a.L.Ptot, 64);
-            launch(l == 0 ? TFK_L1_FACTOR : TFK_BT_FACTOR, gx, 2, 64, &a, sizeof(a));
+            if (l == 0) launch(TFK_L1_FACTOR, gx, 2, 64, &a, sizeof(a));
+            else {
+                launch(TFK_BT_LU, gx, 2, 64, &a, sizeof(a));
+                launch(TFK_BT_SPIKE, gx, 2 * (unsigned)levels[l]->B, 64, &a, sizeof(a));
+            }
             launch(l == 0 ? TFK_L1_ASM_MAT : TFK_BT_ASM_MAT, gx, 1, 64, &a, sizeof(a));
         }
         TfTopArgs t;
@@ -269,7 +273,7 @@ struct tf_solver {
         for (size_t l = 0; l < levels.size(); ++l) {
             TfLevelArgs a = level_args(l, rhs1, x1);
             unsigned gx = cdiv(a.L.Ptot, 64);
-            launch(l == 0 ? TFK_L1_SOLVE : TFK_BT_SOLVE, gx, 2, 64, &a, sizeof(a));
+            launch(l == 0 ? TFK_L1_SOLVE : TFK_BT_RHS, gx, 2, 64, &a, sizeof(a));
             launch(l == 0 ? TFK_L1_ASM_RHS : TFK_BT_ASM_RHS, gx, 1, 64, &a, sizeof(a));
         }
         TfTopArgs t;
@@ -404,6 +408,8 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
         lv.tips_up.alloc(tipsz, tot);
         if (l > 0) {
             lv.Ablk.alloc((size_t)3 * B * B * pl, tot);
+            lv.Dinv.alloc((size_t)2 * B * B * pl, tot);
+            lv.Unup.alloc((size_t)B * B * pl, tot);
             lv.rhs.alloc((size_t)B * pl, tot);
             lv.x.alloc((size_t)B * pl, tot);
         }

@@ -1,0 +1,193 @@
+"""Resident device state behind the schemes (host side of seam #2).
+
+A :class:`Stepper` owns the state slots of one ``tf_solver`` and decides, for
+every ``scheme(t, fields, dt, pars, hook)`` call, whether the incoming
+``fields`` are already on the GPU (they are the container a previous step of
+this stepper returned and nobody touched them on the host) or have to be
+uploaded.  Containers returned by a step are *device backed*
+(``fields.py``): their arrays are downloaded only when read.
+
+``hook`` handling (reference call sites ``schemes.py:139,145,549,558``):
+
+* ``null_hook``                      nothing to do;
+* a :class:`DirichletHook`           applied by a kernel at the places the
+                                     reference calls ``hook`` (no host traffic);
+* any other callable                 the generic, slow path: the fields are
+                                     brought to the host, the callable runs
+                                     there, the result is uploaded again.
+"""
+
+import weakref
+
+import numpy as np
+
+
+def null_hook(t, fields, pars):
+    return fields, pars
+
+
+class DirichletHook:
+    """Declarative boundary hook, e.g. ``DirichletHook(U={0: 1.0, -1: 0.0})``.
+
+    Equivalent to the reference idiom (``README.md:126-129``)::
+
+        def hook(t, fields, pars):
+            fields["U"][0] = 1; fields["U"][-1] = 0
+            return fields, pars
+
+    and usable as such on host containers, but recognised by the device schemes
+    and applied in place on the GPU.
+    """
+
+    def __init__(self, **values):
+        self.values = {var: dict(nodes) for var, nodes in values.items()}
+
+    def __call__(self, t, fields, pars):
+        for var, nodes in self.values.items():
+            for node, value in nodes.items():
+                fields[var][node] = value
+        return fields, pars
+
+    def entries(self, dependent_variables):
+        out = []
+        for var, nodes in self.values.items():
+            idx = list(dependent_variables).index(var)
+            out.extend((idx, int(node), float(value)) for node, value in nodes.items())
+        return out
+
+
+class DeviceBacking:
+    """What a device-backed Fields container points at."""
+
+    def __init__(self, stepper, slot, version):
+        self.stepper, self.slot, self.version = stepper, slot, version
+
+    def valid(self):
+        return self.stepper.slot_version[self.slot] == self.version
+
+    def register(self, fields):
+        """Another container (a copy) now depends on this slot."""
+        self.stepper._users[self.slot].append(weakref.ref(fields))
+
+    def download(self, fields):
+        if not self.valid():
+            raise RuntimeError("device state of this Fields container was recycled "
+                               "(internal error: it should have been saved first)")
+        self.stepper.download_into(fields, self.slot)
+
+
+class Stepper:
+    def __init__(self, compiled, N, periodic, parvec_mask, nstate=4, **opts):
+        self.compiled = compiled
+        self.solver = compiled.solver(N, periodic, 1, parvec_mask, nstate=nstate, **opts)
+        self.nstate = nstate
+        self.slot_version = [0] * nstate
+        self._users = [[] for _ in range(nstate)]       # weakrefs of attached containers
+        self._age = [0] * nstate
+        self._clock = 0
+        self._bound_pars = None
+        self._bound_x = None
+        self._dirichlet = None
+
+    # ---- slots ------------------------------------------------------------------
+    def _live_users(self, slot):
+        alive = []
+        for ref in self._users[slot]:
+            f = ref()
+            if f is not None:
+                b = f._device_backing()
+                if b is not None and b.stepper is self and b.slot == slot \
+                        and b.version == self.slot_version[slot]:
+                    alive.append(f)
+        self._users[slot] = [weakref.ref(f) for f in alive]
+        return alive
+
+    def free_slot(self, exclude=()):
+        """A slot nobody refers to; if every slot is referenced, the least
+        recently written one is saved to its containers first."""
+        candidates = [s for s in range(self.nstate) if s not in exclude]
+        for s in sorted(candidates, key=lambda k: self._age[k]):
+            if not self._live_users(s):
+                return self._claim(s)
+        s = min(candidates, key=lambda k: self._age[k])
+        for f in self._live_users(s):
+            f._materialise()
+        return self._claim(s)
+
+    def _claim(self, slot):
+        self.slot_version[slot] += 1
+        self._clock += 1
+        self._age[slot] = self._clock
+        self._users[slot] = []
+        return slot
+
+    def resident_slot(self, fields):
+        b = fields._device_backing()
+        if b is not None and b.stepper is self and b.valid():
+            return b.slot
+        return None
+
+    def acquire(self, fields, exclude=()):
+        """Slot holding the dependent variables of ``fields`` (uploads if needed)."""
+        slot = self.resident_slot(fields)
+        if slot is not None:
+            return slot
+        slot = self.free_slot(exclude)
+        dep = self.compiled.model._dep_vars
+        self.solver.set_state(slot, np.array([np.asarray(fields[k]) for k in dep]))
+        return slot
+
+    def wrap(self, template, slot):
+        """New container for the state in ``slot`` (coordinates and help functions
+        shared with ``template`` until it is read)."""
+        new = template._device_child(DeviceBacking(self, slot, self.slot_version[slot]))
+        self._users[slot].append(weakref.ref(new))
+        return new
+
+    def download_into(self, fields, slot):
+        arr = self.solver.get_state(slot)
+        fields._fill_from_device(self.compiled.model._dep_vars, arr[:, 0, :])
+
+    # ---- inputs ------------------------------------------------------------------
+    def bind(self, fields, pars):
+        """dx / x / parameters / help functions -> device (skipped when unchanged)."""
+        cm = self.compiled
+        x = np.asarray(fields["x"])
+        xkey = (x.size, float(x[0]), float(x[-1]))
+        values = [pars[k] for k in cm.pars]        # KeyError for a missing parameter
+        mask = self.solver.model.spec["parvec_mask"]
+        scalar = all(np.ndim(v) == 0 or np.size(v) == 1 for v in values)
+        pkey = tuple(float(np.ravel(v)[0]) for v in values) if scalar and not mask else None
+        helper_free = cm.nh == 0
+        if helper_free and pkey is not None and pkey == self._bound_pars and xkey == self._bound_x:
+            return
+        helpers = None if helper_free else [np.asarray(fields[k]) for k in cm.model._help_funcs]
+        cm.bind_inputs(self.solver, x, values, helpers)
+        self._bound_pars, self._bound_x = pkey, xkey
+
+    def set_hook(self, hook):
+        entries = tuple(hook.entries(self.compiled.model._dep_vars)) \
+            if isinstance(hook, DirichletHook) else ()
+        if entries != self._dirichlet:
+            self.solver.set_dirichlet(entries)
+            self._dirichlet = entries
+
+
+def stepper_for(model, fields, pars, **opts):
+    """The Stepper matching ``fields`` / ``pars`` (cached on the compiled model)."""
+    compiled = getattr(model, "_device", None)
+    if compiled is None:
+        raise RuntimeError(
+            "this scheme runs on the GPU and needs a model compiled with the HIP "
+            "compiler (Model(..., compiler='hip')); got a model without device code")
+    b = fields._device_backing()
+    if b is not None and b.valid() and b.stepper.compiled is compiled:
+        return b.stepper
+    values = [pars[k] for k in compiled.pars]
+    mask = compiled.parvec_mask_of(values)
+    periodic = bool(pars["periodic"])
+    key = (fields.size, periodic, mask, tuple(sorted(opts.items())))
+    cache = compiled.__dict__.setdefault("_steppers", {})
+    if key not in cache:
+        cache[key] = Stepper(compiled, fields.size, periodic, mask, **opts)
+    return cache[key]

@@ -1,0 +1,314 @@
+"""Temporal schemes running on the GPU (seam #2 of the reference).
+
+Same classes, constructor arguments and call protocol as
+``triflow/core/schemes.py``::
+
+    scheme = schemes.RODASPR(model, tol=1e-1)
+    t, fields = scheme(t, fields, dt, pars, hook=hook)
+
+but a step is a handful of kernel launches on the state that already lives in
+HBM (``device.py``): the F/J stencil sweep, the banded factorisation of
+``I - gamma dt J``, the stage solves and the vector algebra.  The host sees at
+most one scalar per step (the embedded error estimate of the adaptive
+Rosenbrock schemes).  ``hook`` semantics and call sites are the reference's
+(``schemes.py:139,145,224,549,558``); see ``device.py`` for how declarative
+and arbitrary Python hooks are served.
+
+* Theta        ``schemes.py:502-559``   -> ``tf_step_theta``
+* ROW_general  ``schemes.py:69-238``    -> ``tf_step_row`` (+ host step control)
+* ROS2 / ROS3PRw / ROS3PRL / RODASPR    tableaux of ``schemes.py:241-427``
+* time_stepping ``schemes.py:33-66``    step-doubling wrapper (host logic)
+* scipy_ode    ``schemes.py:430-499``   SciPy integrators fed by ``model.F`` / ``model.J``
+* BDF2         new (named by BASELINE.json, absent from the reference)
+"""
+
+import logging
+from functools import wraps
+
+import numpy as np
+
+from .device import DirichletHook, null_hook, stepper_for
+from .tableaux import TABLEAUX
+
+log = logging.getLogger(__name__)
+log.addHandler(logging.NullHandler())
+
+__all__ = ["null_hook", "DirichletHook", "time_stepping", "Theta", "ROW_general", "ROS2",
+           "ROS3PRw", "ROS3PRL", "RODASPR", "BDF2", "scipy_ode"]
+
+
+def _is_device_hook(hook):
+    return hook is null_hook or isinstance(hook, DirichletHook) or \
+        getattr(hook, "__name__", "") == "null_hook"
+
+
+def _device_step(model, t, fields, pars, hook, launch):
+    """Common prologue of every scheme: resident source slot (uploading when the
+    caller handed over host data), hook at ``t``, one device step into a free
+    slot.  ``launch(solver, src, dst)`` issues the kernels; returns
+    ``(new_fields, pars, launch result)``."""
+    if _is_device_hook(hook):
+        stepper = stepper_for(model, fields, pars)
+        stepper.bind(fields, pars)
+        stepper.set_hook(hook)
+        src = stepper.acquire(fields)
+        template = fields
+    else:
+        # arbitrary Python hook: run it on a host copy (reference: fields =
+        # fields.copy(); fields, pars = hook(t, fields, pars))
+        template, pars = hook(t, fields.copy(), pars)
+        stepper = stepper_for(model, template, pars)
+        stepper.bind(template, pars)
+        stepper.set_hook(null_hook)
+        src = stepper.acquire(template)
+    dst = stepper.free_slot(exclude=(src,))
+    out = launch(stepper.solver, src, dst)
+    return stepper.wrap(template, dst), pars, out
+
+
+def time_stepping(scheme, tol=1e-1, ord=2, m=10, reject_factor=2):
+    """Step-doubling control around any scheme (``schemes.py:33-66``): a coarse
+    step ``m*dt`` against ten fine steps (the reference's literal 10), error
+    ``max_var ||coarse - fine||_ord / (m**2 - 1)``, new ``dt`` from
+    ``sqrt(dt**2 * tol / err)``, retried while it shrinks by more than
+    ``reject_factor``.  The internal ``dt`` persists across calls."""
+    state = {"dt": None}
+
+    def one_step(t, fields, dt, pars, hook):
+        dt_ = dt
+        while True:
+            _, coarse = scheme(t, fields, m * dt_, pars, hook)
+            for _ in range(10):
+                t, fields = scheme(t, fields, dt_, pars, hook)
+            err = max(np.linalg.norm(np.asarray(coarse[key]) - np.asarray(fields[key]), ord)
+                      / (m ** 2 - 1) for key in fields.dependent_variables)
+            dt_ = np.sqrt(dt ** 2 * tol / err)
+            if dt_ < dt / reject_factor:
+                continue        # as in the reference, the retry starts from the advanced state
+            return t, fields, dt_
+
+    @wraps(scheme)
+    def adaptive_scheme(t, fields, dt, pars, hook=null_hook):
+        target = t + dt
+        state["dt"] = state["dt"] if state["dt"] else dt
+        while t + state["dt"] <= target:
+            t, fields, state["dt"] = one_step(t, fields, state["dt"] / m, pars, hook)
+        if t < target:
+            t, fields = scheme(t, fields, target - t, pars, hook)
+        return t, fields
+    return adaptive_scheme
+
+
+class Theta:
+    """Theta scheme (0: forward Euler, 1: backward Euler, 0.5: Crank-Nicolson),
+    ``schemes.py:502-559``.  ``solver`` (seam #3) defaults to the on-device
+    banded solver; a callable ``solver(A, b) -> x`` makes the scheme assemble
+    ``A`` and ``b`` from the device-evaluated ``model.F`` / ``model.J`` and
+    hand them to it, like the reference does."""
+
+    def __init__(self, model, theta=1, solver=None):
+        self._model, self._theta, self._solver = model, theta, solver
+
+    def __call__(self, t, fields, dt, pars, hook=null_hook):
+        if self._solver is not None:
+            return self._host_solver_step(t, fields, dt, pars, hook)
+        new, pars, _ = _device_step(
+            self._model, t, fields, pars, hook,
+            lambda solver, src, dst: solver.step_theta(src, dst, dt, self._theta))
+        if not _is_device_hook(hook):
+            new, _ = hook(t + dt, new, pars)
+        return t + dt, new
+
+    def _host_solver_step(self, t, fields, dt, pars, hook):
+        import scipy.sparse as sps
+        fields = fields.copy()
+        fields, pars = hook(t, fields, pars)
+        F = self._model.F(fields, pars)
+        J = self._model.J(fields, pars)
+        U = fields.uflat
+        B = dt * (F - self._theta * J @ U) + U
+        A = sps.identity(U.size, format="csc") - self._theta * dt * J
+        fields.fill(self._solver(A, B))
+        fields, _ = hook(t + dt, fields, pars)
+        return t + dt, fields
+
+
+class ROW_general:
+    """Rosenbrock-Wanner schemes (``schemes.py:69-238``): one factorisation of
+    ``I - gamma_00 dt J`` per step, ``s`` stage solves."""
+
+    def __init__(self, model, alpha, gamma, b, b_pred=None, time_stepping=False,
+                 tol=None, max_iter=None, dt_min=None, safety_factor=0.9,
+                 recompute_target=True):
+        self._model = model
+        self._alpha = np.asarray(alpha, dtype=float)
+        self._gamma = np.asarray(gamma, dtype=float)
+        self._b = np.asarray(b, dtype=float)
+        self._b_pred = None if b_pred is None else np.asarray(b_pred, dtype=float)
+        self._s = len(b)
+        self._time_control = time_stepping
+        self._tol, self._max_iter, self._dt_min = tol, max_iter, dt_min
+        self._safety_factor = safety_factor
+        self._recompute_target = recompute_target
+        self._internal_dt = None
+        self._internal_iter = None
+        self._interp_cache = None
+        self._err = None
+
+    def __call__(self, t, fields, dt, pars, hook=null_hook):
+        if self._time_control:
+            return self._variable_step(t, fields, dt, pars, hook=hook)
+        t, fields, _ = self._fixed_step(t, fields, dt, pars, hook=hook, hook_after=True,
+                                        want_err=False)
+        return t, fields
+
+    def _fixed_step(self, t, fields, dt, pars, hook=null_hook, hook_after=False,
+                    want_err=True):
+        """``schemes.py:142-174``; returns ``(t + dt, fields, err)`` with
+        ``err = ||U - U_pred||_inf`` when the tableau has ``b_pred``.
+        ``hook_after`` is the extra hook call of the fixed-step ``__call__``
+        (``schemes.py:137-140``)."""
+        device_hook = _is_device_hook(hook)
+
+        def launch(solver, src, dst):
+            return solver.step_row(src, dst, dt, self._alpha, self._gamma, self._b,
+                                   self._b_pred, hook_after=hook_after and device_hook,
+                                   want_err=want_err and self._b_pred is not None)
+        new, pars, err = _device_step(self._model, t, fields, pars, hook, launch)
+        if hook_after and not device_hook:
+            new, pars = hook(t + dt, new, pars)
+        return t + dt, new, err
+
+    def _variable_step(self, t, fields, dt, pars, hook=null_hook):
+        """Embedded-error step control (``schemes.py:176-238``)."""
+        if self._b_pred is None:
+            raise NotImplementedError("time stepping needs the b predictor coefficients")
+        if self._tol is None:
+            raise ValueError("time stepping needs a tolerance")
+        target = t + dt
+        self._internal_iter = 0
+        if self._interp_cache is not None:
+            t0, t1, U0, U1 = self._interp_cache
+            if t0 <= target <= t1:
+                fields.fill(U0 + (U1 - U0) * ((target - t0) / (t1 - t0)))
+                return target, fields
+        start = 1e-6 if self._internal_dt is None else self._internal_dt
+        dt = self._internal_dt = min(start, dt) if self._recompute_target else start
+        while True:
+            self._err = None
+            while self._err is None or self._err > self._tol:
+                new_t, new_fields, self._err = self._fixed_step(t, fields, dt, pars, hook)
+                log.debug("error: %s", self._err)
+                with np.errstate(divide="ignore"):      # err == 0 -> dt = inf, as in NumPy
+                    dt = self._internal_dt = (self._safety_factor * dt
+                                              * np.sqrt(self._tol / self._err))
+            if new_t >= target:
+                self._internal_iter += 1
+                if self._recompute_target:
+                    # land exactly on the target; the closing hook call of
+                    # schemes.py:224 is the step's hook_after
+                    t, fields, self._err = self._fixed_step(t, fields, target - t, pars, hook,
+                                                            hook_after=True)
+                else:
+                    U0, U1 = fields.uflat, new_fields.uflat
+                    self._interp_cache = (t, new_t, U0, U1)
+                    fields = fields.copy()
+                    fields.fill(U0 + (U1 - U0) * ((target - t) / (new_t - t)))
+                    fields, pars = hook(t, fields, pars)
+                return target, fields
+            t, fields = new_t, new_fields
+            self._internal_iter += 1
+            if self._internal_iter > (self._max_iter if self._max_iter
+                                      else self._internal_iter + 1):
+                raise RuntimeError("Rosebrock internal iteration "
+                                   "above max iterations authorized")
+            if dt < (self._dt_min if self._dt_min else dt * .5):
+                raise RuntimeError("Rosebrock internal time step "
+                                   "less than authorized")
+
+
+class ROS2(ROW_general):
+    """Second order, fixed step (``schemes.py:241-256``)."""
+
+    def __init__(self, model):
+        tab = TABLEAUX["ROS2"]
+        super().__init__(model, tab.alpha, tab.gamma, tab.b, time_stepping=False)
+
+
+def _adaptive_row(name, doc):
+    tab = TABLEAUX[name]
+
+    def __init__(self, model, tol=1e-1, time_stepping=True, max_iter=None, dt_min=None,
+                 recompute_target=True):
+        ROW_general.__init__(self, model, tab.alpha, tab.gamma, tab.b, b_pred=tab.b_pred,
+                             time_stepping=time_stepping, tol=tol, max_iter=max_iter,
+                             dt_min=dt_min, recompute_target=recompute_target)
+    return type(name, (ROW_general,), {"__init__": __init__, "__doc__": doc})
+
+
+ROS3PRw = _adaptive_row("ROS3PRw", "Third order, 3 stages, adaptive (schemes.py:259-300).")
+ROS3PRL = _adaptive_row("ROS3PRL", "Fourth order, 4 stages, adaptive (schemes.py:303-353).")
+RODASPR = _adaptive_row("RODASPR", "Sixth order, 6 stages, adaptive (schemes.py:356-427).")
+
+
+class BDF2:
+    """Linearly implicit two-step BDF, fixed step (new; scheme protocol of
+    ``schemes.py:523-559``)::
+
+        (I - 2/3 dt J(U_n)) (U_{n+1} - U_n) = 1/3 (U_n - U_{n-1}) + 2/3 dt F(U_n)
+
+    The first call, and any call whose ``dt`` differs from the previous one,
+    is the backward-Euler form ``(I - dt J)(U_{n+1} - U_n) = dt F``.  The
+    history ``U_{n-1}`` lives on the device next to the state."""
+
+    def __init__(self, model):
+        self._model = model
+        self._stepper = None
+
+    def __call__(self, t, fields, dt, pars, hook=null_hook):
+        def launch(solver, src, dst):
+            if self._stepper is not solver:
+                solver.bdf2_reset()
+                self._stepper = solver
+            solver.step_bdf2(src, dst, dt)
+        new, pars, _ = _device_step(self._model, t, fields, pars, hook, launch)
+        if not _is_device_hook(hook):
+            new, _ = hook(t + dt, new, pars)
+        return t + dt, new
+
+    def reset(self):
+        if self._stepper is not None:
+            self._stepper.bdf2_reset()
+
+
+class scipy_ode:
+    """Proxy around ``scipy.integrate.ode`` (``schemes.py:430-499``): the
+    integrator runs on the host and calls the device-evaluated ``model.F``
+    (and the dense ``model.J`` when ``jac=True``)."""
+
+    def __init__(self, model, jac=False, integrator="vode", **integrator_kwargs):
+        from scipy.integrate import ode
+
+        def func(t, U, fields, pars, hook):
+            fields.fill(U)
+            fields, pars = hook(t, fields, pars)
+            return model.F(fields, pars)
+
+        def jacob(t, U, fields, pars, hook):
+            fields.fill(U)
+            fields, pars = hook(t, fields, pars)
+            return model.J(fields, pars, sparse=False)
+
+        self._solv = ode(func, jac=jacob if jac else None)
+        self._solv.set_integrator(integrator, **integrator_kwargs)
+
+    def __call__(self, t, fields, dt, pars, hook=null_hook):
+        solv = self._solv
+        fields, pars = hook(t, fields, pars)
+        solv.set_initial_value(fields.uflat, t)
+        solv.set_f_params(fields, pars, hook)
+        solv.set_jac_params(fields, pars, hook)
+        U = solv.integrate(t + dt)
+        fields.fill(U)
+        fields, _ = hook(t + dt, fields, pars)
+        return t + dt, fields
