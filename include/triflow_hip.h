@@ -53,7 +53,9 @@ typedef struct tf_solver_opts {
     int32_t m1;           /* chunk length of the first solver level (0 = default)   */
     int32_t m_upper;      /* chunk length of the reduced levels     (0 = default)   */
     int32_t nstate;       /* resident state slots                   (0 = default 3) */
-    int32_t refine;       /* iterative-refinement sweeps per linear solve           */
+    int32_t refine;       /* refinement sweeps per solve; 0 = none, -1 = automatic:
+                             measure the backward error of the first solve after
+                             each factorisation and polish only if it is > 1e-14   */
     int32_t device;       /* HIP device ordinal (-1 = current)                      */
 } tf_solver_opts;
 
@@ -101,15 +103,15 @@ int tf_matvec(tf_solver*, const double* v_flat, double* y_flat);     /* y = J @ 
 /* ---- seam #2: one time step, state slot src -> slot dst --------------------- */
 int tf_step_theta(tf_solver*, int32_t src, int32_t dst, double dt, double theta);
 /* alpha, gamma: [s][s] row major; b, b_pred: [s] (b_pred may be NULL);
- * err_out (may be NULL) receives ||U - U_pred||_inf per system [nsys];
+ * err_out (may be NULL) receives ||U - U_pred||_inf, one scalar over all systems;
  * hook_after: apply the Dirichlet list to the result (fixed-step __call__) */
 int tf_step_row(tf_solver*, int32_t src, int32_t dst, double dt, int32_t s,
                 const double* alpha, const double* gamma, const double* b,
                 const double* b_pred, int32_t hook_after, double* err_out);
 int tf_step_bdf2(tf_solver*, int32_t src, int32_t dst, double dt);
 int tf_bdf2_reset(tf_solver*);
-/* ||state[a] - state[b]||_ord per dependent variable and system, [nsys][nvar]
- * (error estimate of the step-doubling wrapper, schemes.py:41-44); ord 2 or inf(0) */
+/* max |state[a] - state[b]| over all variables and systems (one scalar); only
+ * ord = 0 (the max norm) is implemented on the device */
 int tf_diff_norm(tf_solver*, int32_t slot_a, int32_t slot_b, int32_t ord, double* out);
 
 int tf_sync(tf_solver*);            /* waits for the stream, reports device-side failures */

@@ -14,7 +14,7 @@ def declared_symbols():
     with open(os.path.join(ROOT, "include", "triflow_hip.h")) as f:
         text = f.read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(tf_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(tf_[A-Za-z0-9_]+)\s*\(", text)))
 
 
 def test_header_and_binding_agree():
@@ -26,7 +26,7 @@ def test_library_builds_and_exports_every_symbol():
     lib_path = compilers.build_runtime_library()
     out = subprocess.run(["nm", "-D", "--defined-only", lib_path], capture_output=True,
                          text=True, check=True).stdout
-    exported = set(re.findall(r" T (tf_[a-z0-9_]+)", out))
+    exported = set(re.findall(r" T (tf_[A-Za-z0-9_]+)", out))
     assert set(declared_symbols()) <= exported
     lib = _capi.Library(lib_path)          # loads, binds every entry point
     assert lib.dll.tf_kernel_count() == len(lib.kernel_names())
@@ -62,8 +62,8 @@ def test_code_object_holds_every_kernel():
     from triflow_amd import Model
     m = Model("k * dxxU", "U", "k", hold_compilation=True)
     hsaco, spec = compilers.build_code_object(m)
-    syms = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-nm", hsaco], capture_output=True,
-                          text=True, check=True).stdout
+    syms = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "-s", hsaco],
+                          capture_output=True, text=True, check=True).stdout
     lib = _capi.Library(compilers.build_runtime_library())
     for name in lib.kernel_names():
         assert re.search(r"\b%s\b" % name, syms), name

@@ -16,7 +16,8 @@ def backend():
     return EmuBackend()
 
 
-FJ_MODELS = ["M1_advdiff", "M2_diff", "bivar", "helper_d", "upwind3_par", "upwind2_state",
+FJ_MODELS = ["M1_advdiff", "M2_diff", "heat_nopar", "bivar", "helper", "helper_d",
+             "upwind1_const", "upwind2_par", "upwind3_par", "upwind2_state", "burgers", "kdv",
              "kuramoto", "wave", "nonlin", "M3_film", "M5_stiff"]
 
 

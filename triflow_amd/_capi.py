@@ -142,7 +142,7 @@ class DeviceSolver:
     """``tf_solver``: resident state + kernels for ``nsys`` systems of ``N`` nodes."""
 
     def __init__(self, model, N, nsys=1, periodic=False, m1=0, m_upper=0, nstate=0,
-                 refine=0, device=-1):
+                 refine=-1, device=-1):
         self.model = model
         self.lib = model.lib
         self.N, self.nsys, self.periodic = int(N), int(nsys), bool(periodic)

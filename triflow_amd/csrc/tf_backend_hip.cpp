@@ -35,7 +35,10 @@ void* dev_alloc(size_t bytes) {
     void* p = nullptr;
     if (bytes == 0) bytes = 8;
     TF_HIP(hipMalloc(&p, bytes));
+    // the solver streams are non-blocking: make sure the zero fill (null stream)
+    // has landed before anything is uploaded into the new buffer
     TF_HIP(hipMemset(p, 0, bytes));
+    TF_HIP(hipDeviceSynchronize());
     return p;
 }
 void dev_free(void* p) { if (p) (void)hipFree(p); }

@@ -28,8 +28,12 @@ TF_DEVICE double tf_powi(double x, int n) {
         lo = e - (s - p);
         hi = s;
     }
-    double r = hi + lo;
-    return neg ? 1.0 / r : r;
+    if (!neg) return hi + lo;
+    // 1 / (hi + lo), corrected with the exact residual of the rounded quotient
+    double q = 1.0 / hi;
+    double r = __builtin_fma(-hi, q, 1.0);
+    r = __builtin_fma(-lo, q, r);
+    return __builtin_fma(r, q, q);
 }
 TF_DEVICE double tf_max(double a, double b) { return (a > b || a != a) ? a : b; }   // np.maximum
 TF_DEVICE double tf_min(double a, double b) { return (a < b || a != a) ? a : b; }   // np.minimum

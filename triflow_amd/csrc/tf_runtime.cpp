@@ -103,6 +103,8 @@ struct tf_solver {
     DevBuf topAinv;
     double factor_c = 0.0;
     bool have_factor = false, have_jac = false;
+    bool fact_checked = false, fact_needs_refine = false;   // refine == -1 (auto)
+    double last_omega = 0.0;
 
     // declarative Dirichlet hook
     int ndir = 0;
@@ -168,11 +170,11 @@ struct tf_solver {
 
     // ------------------------------------------------------ elementary steps
     void vec(int op, double* out, const double* base, int nterms, const double* const* xs,
-             const double* cs, int64_t n = -1) {
+             const double* cs, int64_t n = -1, int red_slot = 0) {
         TfVecArgs a;
         std::memset(&a, 0, sizeof(a));
         a.n = n < 0 ? vecn() : n;
-        a.nterms = nterms; a.op = op; a.out = out; a.base = base; a.red = red.p;
+        a.nterms = nterms; a.op = op; a.out = out; a.base = base; a.red = red.p + red_slot;
         for (int t = 0; t < nterms; ++t) { a.x[t] = xs[t]; a.c[t] = cs ? cs[t] : 1.0; }
         unsigned grid = std::min<unsigned>(cdiv(a.n, 256), 2048u);
         launch(op == TF_VEC_MAXABS ? TFK_VEC_MAXABS : TFK_VEC, std::max(grid, 1u), 1, 256, &a, sizeof(a));
@@ -268,6 +270,8 @@ struct tf_solver {
         t.nsys = nsys; t.A = top.Ablk.p; t.rhs = top.rhs.p; t.Ainv = topAinv.p; t.x = top.x.p; t.status = status;
         launch(TFK_TOP_FACTOR, cdiv(nsys, 64), 1, 64, &t, sizeof(t));
         have_factor = true;
+        fact_checked = false;
+        fact_needs_refine = false;
     }
     void solve_once(const double* rhs1, double* x1) {
         for (size_t l = 0; l < levels.size(); ++l) {
@@ -284,17 +288,49 @@ struct tf_solver {
             launch(l == 0 ? TFK_L1_BACKSUB : TFK_BT_BACKSUB, cdiv(a.L.Ptot, 64), 1, 64, &a, sizeof(a));
         }
     }
-    // x = (I - c J)^-1 rhs, optionally polished by iterative refinement
+    void refine_sweep(const double* rhs1, double* x1) {
+        spmv(x1, Wjv.p, factor_c);                               // c J x
+        const double* xs[3] = {rhs1, x1, Wjv.p};
+        vec(TF_VEC_RESID, Wres.p, nullptr, 3, xs, nullptr);      // r = (b - x) + c J x
+        solve_once(Wres.p, Wdel.p);
+        const double* ys[2] = {x1, Wdel.p};
+        vec(TF_VEC_ADD, x1, nullptr, 2, ys, nullptr);
+    }
+    // normwise backward error  ||b - A x||_inf / (||x||_inf + ||c J x||_inf)
+    double backward_error(const double* rhs1, const double* x1) {
+        spmv(x1, Wjv.p, factor_c);
+        const double* xs[3] = {rhs1, x1, Wjv.p};
+        vec(TF_VEC_RESID, Wres.p, nullptr, 3, xs, nullptr);
+        tfb::memset0(red.p, 3 * sizeof(double), stream);
+        const double one[1] = {1.0};
+        const double* a0[1] = {Wres.p}; const double* a1[1] = {x1}; const double* a2[1] = {Wjv.p};
+        vec(TF_VEC_MAXABS, nullptr, nullptr, 1, a0, one, -1, 0);
+        vec(TF_VEC_MAXABS, nullptr, nullptr, 1, a1, one, -1, 1);
+        vec(TF_VEC_MAXABS, nullptr, nullptr, 1, a2, one, -1, 2);
+        double h[3] = {0, 0, 0};
+        tfb::d2h(h, red.p, sizeof(h), stream);
+        const double den = h[1] + h[2];
+        return den > 0 ? h[0] / den : h[0];
+    }
+    // x = (I - c J)^-1 rhs.  refine > 0: that many refinement sweeps; refine == -1
+    // (default): the first solve after every factorisation measures the backward
+    // error, and only a factorisation that lost accuracy (block elimination does
+    // not pivot across blocks) is polished, this solve and the following ones.
     void solve(const double* rhs1, double* x1) {
         if (!have_factor) throw std::runtime_error("tf_solve: matrix not factorised");
         solve_once(rhs1, x1);
-        for (int it = 0; it < refine; ++it) {
-            spmv(x1, Wjv.p, factor_c);                               // c J x
-            const double* xs[3] = {rhs1, x1, Wjv.p};
-            vec(TF_VEC_RESID, Wres.p, nullptr, 3, xs, nullptr);      // r = (b - x) + c J x
-            solve_once(Wres.p, Wdel.p);
-            const double* ys[2] = {x1, Wdel.p};
-            vec(TF_VEC_ADD, x1, nullptr, 2, ys, nullptr);
+        if (refine > 0) {
+            for (int it = 0; it < refine; ++it) refine_sweep(rhs1, x1);
+        } else if (refine < 0) {
+            if (!fact_checked) {
+                last_omega = backward_error(rhs1, x1);
+                fact_checked = true;
+                fact_needs_refine = !(last_omega <= 1e-14);
+            }
+            if (fact_needs_refine) {
+                refine_sweep(rhs1, x1);
+                refine_sweep(rhs1, x1);
+            }
         }
     }
 
@@ -353,7 +389,7 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
     int m1 = opts && opts->m1 > 0 ? opts->m1 : 32;
     int mup = opts && opts->m_upper > 0 ? opts->m_upper : 8;
     s->nstate = opts && opts->nstate > 0 ? opts->nstate : 3;
-    s->refine = opts && opts->refine > 0 ? opts->refine : 0;
+    s->refine = opts ? opts->refine : -1;      // 0 = never, n > 0 = fixed sweeps, -1 = auto
     if (opts && opts->device >= 0) tfb::set_device(opts->device);
     m1 = std::max(m1, 2 * sp.mp);
     mup = std::max(mup, 2);
