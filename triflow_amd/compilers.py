@@ -90,7 +90,7 @@ def build_code_object(model, parvec_mask=0, seg=None, sweep_block=None):
     body, spec = codegen.lower_model(model, parvec_mask=parvec_mask, seg=seg,
                                      sweep_block=sweep_block)
     source = _TU_HEAD + body + _TU_TAIL
-    tag = codegen.source_hash(source, _skeleton_stamp(), " ".join(HIPCC_FLAGS))
+    tag = codegen.source_hash(source, _skeleton_stamp(), " ".join(HIPCC_FLAGS), "elf")
     os.makedirs(CACHE_DIR, exist_ok=True)
     hsaco = os.path.join(CACHE_DIR, "model_%s.hsaco" % tag)
     if not os.path.exists(hsaco):
@@ -98,7 +98,8 @@ def build_code_object(model, parvec_mask=0, seg=None, sweep_block=None):
         with open(hip, "w") as f:
             f.write(source)
         tmp = hsaco + ".%d.tmp" % os.getpid()
-        cmd = [_hipcc(), *HIPCC_FLAGS, "-I", CSRC, "--genco", "-o", tmp, hip]
+        cmd = [_hipcc(), *HIPCC_FLAGS, "-I", CSRC, "--genco", "--no-gpu-bundle-output",
+               "-o", tmp, hip]
         log.info("hipcc: compiling stencil + solver kernels for %s", model._diff_eqs)
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:

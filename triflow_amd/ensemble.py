@@ -1,0 +1,99 @@
+"""Ensembles / parameter sweeps: many independent 1-D systems in one solver.
+
+The reference has no batch dimension; its guidance for parametric studies is to
+pickle the model and run members in separate processes
+(``source_doc/source/user_guide.rst:125-138``).  Here the members of a sweep
+that live on one GPU share one ``tf_solver`` (``nsys`` systems: the chunks of
+all members sit side by side in the partition-interleaved planes and go through
+the same kernel launches), and a sweep is sharded over the GPUs of a node by
+member index: member ``m`` belongs to rank ``m % world_size``.  Members never
+exchange data; the only collective is the one-off broadcast of the parameter
+table from rank 0 (``broadcast_table``).
+"""
+
+import numpy as np
+
+from .tableaux import TABLEAUX
+
+
+def shard_members(n_members, rank, world_size):
+    """Indices of the ensemble members owned by ``rank`` (round robin)."""
+    return list(range(rank, n_members, world_size))
+
+
+def broadcast_table(table, src=0):
+    """Rank ``src``'s float64 table to every rank through ``torch.distributed``
+    (RCCL when the process group is 'nccl', Gloo on CPU)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return np.asarray(table, dtype=np.float64)
+    device = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.as_tensor(np.ascontiguousarray(table, dtype=np.float64)).to(device)
+    dist.broadcast(t, src=src)
+    return t.cpu().numpy()
+
+
+class Ensemble:
+    """``nsys`` members of the same model on one GPU, stepped together.
+
+    ``fields``: dict name -> array ``[nsys][N]`` (dependent variables and help
+    functions); ``x``: ``[N]`` or ``[nsys][N]``; ``pars``: dict name -> scalar,
+    ``[nsys]`` (one value per member) or ``[nsys][N]``.
+    """
+
+    def __init__(self, model, x, fields, pars, periodic, scheme="ROS2", theta=1.0,
+                 hook=None, device=-1, **solver_opts):
+        cm = getattr(model, "_device", None)
+        if cm is None:
+            raise RuntimeError("Ensemble needs a model compiled with the HIP compiler")
+        self.model, self.compiled = model, cm
+        dep = list(model._dep_vars)
+        first = np.asarray(fields[dep[0]], dtype=float)
+        self.nsys, self.N = (1, first.size) if first.ndim == 1 else first.shape
+        x = np.broadcast_to(np.asarray(x, dtype=float), (self.nsys, self.N))
+        values = []
+        mask = 0
+        for k, name in enumerate(cm.pars):
+            v = np.asarray(pars[name], dtype=float)
+            if v.ndim == 2 or (v.ndim == 1 and v.size == self.N and self.nsys != self.N):
+                v = np.broadcast_to(v, (self.nsys, self.N))
+                mask |= 1 << k
+            values.append(v)
+        self.solver = cm.solver(self.N, periodic, self.nsys, mask, device=device,
+                                **solver_opts)
+        s = self.solver
+        s.set_dx((x[:, -1] - x[:, 0]) / (self.N - 1))
+        s.set_x(x)
+        for k, v in enumerate(values):
+            s.set_param(k, v)
+        if cm.nh:
+            s.set_helpers(np.array([np.broadcast_to(fields[k], (self.nsys, self.N))
+                                    for k in model._help_funcs]))
+        s.set_state(0, np.array([np.broadcast_to(fields[k], (self.nsys, self.N)) for k in dep]))
+        if hook is not None:
+            s.set_dirichlet(hook.entries(dep))
+        self.scheme, self.theta = scheme, theta
+        self.tab = TABLEAUX.get(scheme)
+        self.cur, self.t = 0, 0.0
+
+    def step(self, dt):
+        """One fixed step of every member (asynchronous: returns after the launches)."""
+        s, src = self.solver, self.cur
+        dst = (src + 1) % s.nstate
+        if self.scheme == "Theta":
+            s.step_theta(src, dst, dt, self.theta)
+        elif self.scheme == "BDF2":
+            s.step_bdf2(src, dst, dt)
+        else:
+            s.step_row(src, dst, dt, self.tab.alpha, self.tab.gamma, self.tab.b, None,
+                       hook_after=True, want_err=False)
+        self.cur = dst
+        self.t += dt
+
+    def sync(self):
+        self.solver.sync()
+
+    def state(self):
+        """Dependent variables, ``[nvar][nsys][N]``."""
+        return self.solver.get_state(self.cur)
