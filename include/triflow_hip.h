@@ -55,7 +55,7 @@ typedef struct tf_solver_opts {
     int32_t nstate;       /* resident state slots                   (0 = default 3) */
     int32_t refine;       /* refinement sweeps per solve; 0 = none, -1 = automatic:
                              measure the backward error of the first solve after
-                             each factorisation and polish only if it is > 1e-14   */
+                             each factorisation and polish only if it is > 1e-12   */
     int32_t device;       /* HIP device ordinal (-1 = current)                      */
 } tf_solver_opts;
 
@@ -113,6 +113,11 @@ int tf_bdf2_reset(tf_solver*);
 /* max |state[a] - state[b]| over all variables and systems (one scalar); only
  * ord = 0 (the max norm) is implemented on the device */
 int tf_diff_norm(tf_solver*, int32_t slot_a, int32_t slot_b, int32_t ord, double* out);
+
+/* componentwise backward error max|b-Ax|/(|x|+|cJ||x|+|b|) measured on the first
+ * solve after the last factorisation (refine = -1), and whether it triggered
+ * refinement */
+int tf_backward_error(tf_solver*, double* omega, int32_t* refined);
 
 int tf_sync(tf_solver*);            /* waits for the stream, reports device-side failures */
 

@@ -62,7 +62,7 @@ void launch(Module*, int kernel, unsigned gx, unsigned gy, unsigned block,
         for (int64_t i = 0; i < a.n; ++i) tfk_vec_elem(a, i); } break;
     case TFK_VEC_MAXABS: { const auto& a = *(const TfVecArgs*)args;
         double m = *a.red;
-        for (int64_t i = 0; i < a.n; ++i) { double v = tf_vec_err(a, i); m = (v > m || v != v) ? v : m; }
+        for (int64_t i = 0; i < a.n; ++i) { double v = a.op == TF_VEC_MAXRATIO ? tf_vec_ratio(a, i) : tf_vec_err(a, i); m = (v > m || v != v) ? v : m; }
         *a.red = m; } break;
     case TFK_PERM: { const auto& a = *(const TfPermArgs*)args;
         for (int64_t t = 0; t < nthreads; ++t) tfk_perm_elem(a, t); } break;

@@ -61,6 +61,7 @@ SIGNATURES = {
     "tf_step_bdf2": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double]),
     "tf_bdf2_reset": (C.c_int, [C.c_void_p]),
     "tf_diff_norm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_double_p]),
+    "tf_backward_error": (C.c_int, [C.c_void_p, c_double_p, c_int32_p]),
     "tf_sync": (C.c_int, [C.c_void_p]),
     "tf_timing_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "tf_timing_reset": (C.c_int, [C.c_void_p]),
@@ -284,6 +285,12 @@ class DeviceSolver:
         out = C.c_double(0.0)
         self.lib.call("tf_diff_norm", self.handle, slot_a, slot_b, 0, C.byref(out))
         return out.value
+
+    def backward_error(self):
+        """(componentwise backward error of the checked solve, refinement active?)"""
+        om, flag = C.c_double(0.0), C.c_int32(0)
+        self.lib.call("tf_backward_error", self.handle, C.byref(om), C.byref(flag))
+        return om.value, bool(flag.value)
 
     def sync(self):
         self.lib.call("tf_sync", self.handle)

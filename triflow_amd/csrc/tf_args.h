@@ -47,6 +47,7 @@ struct TfSpmvArgs {                // y = scale * J @ v  (clamped/wrapped column
     const double* v;               // [nvar] planes
     double* y;                     // [nvar] planes
     double scale;
+    int absval;                    // 1: y = |scale J| @ |v|  (componentwise backward error)
 };
 
 struct TfVecArgs {                 // elementwise plane algebra

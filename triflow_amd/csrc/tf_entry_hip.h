@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(256) tfk_vec_maxabs(TfVecArgs a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     double m = 0.0;
     for (int64_t i = TF_GID; i < a.n; i += stride) {
-        const double v = tf_vec_err(a, i);
+        const double v = a.op == TF_VEC_MAXRATIO ? tf_vec_ratio(a, i) : tf_vec_err(a, i);
         m = (v > m || v != v) ? v : m;            // NaN wins, like np.linalg.norm(inf)
     }
     unsigned long long bits = (unsigned long long)__double_as_longlong(m);

@@ -167,8 +167,10 @@ TF_DEVICE void tfk_spmv_body(const TfSpmvArgs& a, int pg, int seg) {
             for (int v = 0; v < TF_NVAR; ++v) acc[v] = 0.0;
 #pragma unroll
             for (int k = 0; k < TF_NNZ; ++k) {       // pattern order = ascending column
-                const double jv = a.scale * a.Jv[(int64_t)k * L.plane + s];
-                acc[tf_pat_eq[k]] = acc[tf_pat_eq[k]] + jv * w[tf_pat_var[k]][tf_pat_off[k] + TF_MP];
+                double jv = a.scale * a.Jv[(int64_t)k * L.plane + s];
+                double wv = w[tf_pat_var[k]][tf_pat_off[k] + TF_MP];
+                if (a.absval) { jv = tf_abs(jv); wv = tf_abs(wv); }
+                acc[tf_pat_eq[k]] = acc[tf_pat_eq[k]] + jv * wv;
             }
 #pragma unroll
             for (int v = 0; v < TF_NVAR; ++v) a.y[(int64_t)v * L.plane + s] = acc[v];
@@ -189,12 +191,18 @@ enum TfVecOp {
     TF_VEC_BDF2_RHS = 5,   // out = c0*(x0 - x1) + c1*x2    1/3 (U - Uprev) + 2/3 dt F
     TF_VEC_ADD = 6,        // out = x0 + x1
     TF_VEC_RESID = 7,      // out = (x0 - x1) + x2          r = b - x + c J x
+    TF_VEC_MAXRATIO = 8,   // red = max |x0| / (|x1| + |x2| + |x3|)   componentwise backward error
 };
 
 TF_DEVICE double tf_vec_sum(const TfVecArgs& a, int64_t i) {
     double acc = a.c[0] * a.x[0][i];
     for (int t = 1; t < a.nterms; ++t) acc = acc + a.c[t] * a.x[t][i];
     return acc;
+}
+TF_DEVICE double tf_vec_ratio(const TfVecArgs& a, int64_t i) {
+    const double num = tf_abs(a.x[0][i]);
+    const double den = tf_abs(a.x[1][i]) + tf_abs(a.x[2][i]) + tf_abs(a.x[3][i]);
+    return num == 0.0 ? 0.0 : num / den;          // x/0 = inf flags a broken row
 }
 // element of the ROW error estimate: |U - U_pred| with U_pred = U + sum_i b_pred_i k_i
 // formed from the updated U (schemes.py:167-174); plain |sum| without a base

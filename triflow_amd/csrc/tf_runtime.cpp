@@ -74,7 +74,7 @@ struct Level {
 // enum values of tf_kernels.h (kept in sync by tests/test_abi.py)
 enum {
     TF_VEC_SUM = 0, TF_VEC_LIN2 = 1, TF_VEC_THETA_RHS = 2, TF_VEC_MAXABS = 3, TF_VEC_COPY = 4,
-    TF_VEC_BDF2_RHS = 5, TF_VEC_ADD = 6, TF_VEC_RESID = 7
+    TF_VEC_BDF2_RHS = 5, TF_VEC_ADD = 6, TF_VEC_RESID = 7, TF_VEC_MAXRATIO = 8
 };
 
 struct tf_model {
@@ -104,7 +104,7 @@ struct tf_solver {
     double factor_c = 0.0;
     bool have_factor = false, have_jac = false;
     bool fact_checked = false, fact_needs_refine = false;   // refine == -1 (auto)
-    double last_omega = 0.0;
+    double last_omega = 0.0, refine_trigger = 1e-12;
 
     // declarative Dirichlet hook
     int ndir = 0;
@@ -177,7 +177,7 @@ struct tf_solver {
         a.nterms = nterms; a.op = op; a.out = out; a.base = base; a.red = red.p + red_slot;
         for (int t = 0; t < nterms; ++t) { a.x[t] = xs[t]; a.c[t] = cs ? cs[t] : 1.0; }
         unsigned grid = std::min<unsigned>(cdiv(a.n, 256), 2048u);
-        launch(op == TF_VEC_MAXABS ? TFK_VEC_MAXABS : TFK_VEC, std::max(grid, 1u), 1, 256, &a, sizeof(a));
+        launch((op == TF_VEC_MAXABS || op == TF_VEC_MAXRATIO) ? TFK_VEC_MAXABS : TFK_VEC, std::max(grid, 1u), 1, 256, &a, sizeof(a));
     }
 
     void perm(int mode, const double* src, double* dst, int ncomp) {
@@ -229,9 +229,9 @@ struct tf_solver {
         launch(with_j ? TFK_SWEEP_FJ : TFK_SWEEP_F, gx, gy, spec.sweep_block, &a, sizeof(a));
         if (with_j) { have_jac = true; have_factor = false; }
     }
-    void spmv(const double* v, double* y, double scale) {
+    void spmv(const double* v, double* y, double scale, bool absval = false) {
         TfSpmvArgs a;
-        a.L = L1; a.Jv = Jv.p; a.v = v; a.y = y; a.scale = scale;
+        a.L = L1; a.Jv = Jv.p; a.v = v; a.y = y; a.scale = scale; a.absval = absval ? 1 : 0;
         unsigned gx = cdiv(L1.Ptot, spec.sweep_block), gy = cdiv(L1.M, spec.seg);
         launch(TFK_SPMV, gx, gy, spec.sweep_block, &a, sizeof(a));
     }
@@ -296,21 +296,19 @@ struct tf_solver {
         const double* ys[2] = {x1, Wdel.p};
         vec(TF_VEC_ADD, x1, nullptr, 2, ys, nullptr);
     }
-    // normwise backward error  ||b - A x||_inf / (||x||_inf + ||c J x||_inf)
+    // componentwise (Oettli-Prager) backward error
+    //   max_i |b - A x|_i / (|x| + |c J||x| + |b|)_i
     double backward_error(const double* rhs1, const double* x1) {
         spmv(x1, Wjv.p, factor_c);
         const double* xs[3] = {rhs1, x1, Wjv.p};
         vec(TF_VEC_RESID, Wres.p, nullptr, 3, xs, nullptr);
-        tfb::memset0(red.p, 3 * sizeof(double), stream);
-        const double one[1] = {1.0};
-        const double* a0[1] = {Wres.p}; const double* a1[1] = {x1}; const double* a2[1] = {Wjv.p};
-        vec(TF_VEC_MAXABS, nullptr, nullptr, 1, a0, one, -1, 0);
-        vec(TF_VEC_MAXABS, nullptr, nullptr, 1, a1, one, -1, 1);
-        vec(TF_VEC_MAXABS, nullptr, nullptr, 1, a2, one, -1, 2);
-        double h[3] = {0, 0, 0};
-        tfb::d2h(h, red.p, sizeof(h), stream);
-        const double den = h[1] + h[2];
-        return den > 0 ? h[0] / den : h[0];
+        spmv(x1, Wjv.p, factor_c, true);
+        tfb::memset0(red.p, sizeof(double), stream);
+        const double* q[4] = {Wres.p, x1, Wjv.p, rhs1};
+        vec(TF_VEC_MAXRATIO, nullptr, nullptr, 4, q, nullptr);
+        double h = 0;
+        tfb::d2h(&h, red.p, sizeof(h), stream);
+        return h;
     }
     // x = (I - c J)^-1 rhs.  refine > 0: that many refinement sweeps; refine == -1
     // (default): the first solve after every factorisation measures the backward
@@ -325,7 +323,7 @@ struct tf_solver {
             if (!fact_checked) {
                 last_omega = backward_error(rhs1, x1);
                 fact_checked = true;
-                fact_needs_refine = !(last_omega <= 1e-14);
+                fact_needs_refine = !(last_omega <= refine_trigger);
             }
             if (fact_needs_refine) {
                 refine_sweep(rhs1, x1);
@@ -749,6 +747,14 @@ int tf_diff_norm(tf_solver* s, int32_t slot_a, int32_t slot_b, int32_t ord, doub
     uint64_t bits = 0;
     tfb::d2h(&bits, s->red.p, sizeof(bits), s->stream);
     std::memcpy(out, &bits, sizeof(double));
+    TF_API_END
+}
+
+int tf_backward_error(tf_solver* s, double* omega, int32_t* refined) {
+    TF_API_BEGIN
+    require(s, "null solver");
+    if (omega) *omega = s->last_omega;
+    if (refined) *refined = s->fact_needs_refine ? 1 : 0;
     TF_API_END
 }
 
