@@ -121,8 +121,9 @@ int tf_backward_error(tf_solver*, double* omega, int32_t* refined);
 
 int tf_sync(tf_solver*);            /* waits for the stream, reports device-side failures */
 
-/* ---- measurement: HIP-event timing of every launch, per kernel ------------- */
-int tf_timing_enable(tf_solver*, int32_t on);
+/* ---- measurement: kernel begin/end timestamps (HIP events attached to the
+ * launch) per kernel; mask bit k selects kernel k, -1 = all, 0 = off ---------- */
+int tf_timing_enable(tf_solver*, int32_t mask);
 int tf_timing_reset(tf_solver*);
 int tf_timing_get(tf_solver*, int32_t kernel, double* total_ms, int64_t* launches);
 int tf_kernel_count(void);

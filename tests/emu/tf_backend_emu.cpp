@@ -64,6 +64,11 @@ void launch(Module*, int kernel, unsigned gx, unsigned gy, unsigned block,
         double m = *a.red;
         for (int64_t i = 0; i < a.n; ++i) { double v = a.op == TF_VEC_MAXRATIO ? tf_vec_ratio(a, i) : tf_vec_err(a, i); m = (v > m || v != v) ? v : m; }
         *a.red = m; } break;
+    case TFK_BERR: { const auto& a = *(const TfBerrArgs*)args;
+        double m = *a.red;
+        for (unsigned y = 0; y < gy; ++y) for (int64_t t = 0; t < nthreads; ++t) {
+            double v = tfk_berr_body(a, (int)t, (int)y); m = (v > m || v != v) ? v : m; }
+        *a.red = m; } break;
     case TFK_PERM: { const auto& a = *(const TfPermArgs*)args;
         for (int64_t t = 0; t < nthreads; ++t) tfk_perm_elem(a, t); } break;
     case TFK_DIRICHLET: { const auto& a = *(const TfDirichletArgs*)args;
@@ -98,6 +103,11 @@ void launch(Module*, int kernel, unsigned gx, unsigned gy, unsigned block,
         for (int64_t t = 0; t < nthreads; ++t) tfk_top_body<TF_B2, false>(a, (int)t); } break;
     default: throw std::runtime_error("emu: unknown kernel");
     }
+}
+
+void launch_timed(Module* m, int kernel, unsigned gx, unsigned gy, unsigned block,
+                  const void* args, size_t n, Stream* s, Event*, Event*) {
+    launch(m, kernel, gx, gy, block, args, n, s);
 }
 
 }  // namespace tfb

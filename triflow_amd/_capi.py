@@ -296,8 +296,16 @@ class DeviceSolver:
         self.lib.call("tf_sync", self.handle)
 
     # ------------------------------------------------------------- measurement
-    def timing(self, on=True):
-        self.lib.call("tf_timing_enable", self.handle, int(on))
+    def timing(self, on=True, kernels=None):
+        """Time every launch (``on=True``), none, or only the named ``kernels``."""
+        if kernels is not None:
+            names = self.lib.kernel_names()
+            mask = 0
+            for k in kernels:
+                mask |= 1 << names.index(k)
+        else:
+            mask = -1 if on else 0
+        self.lib.call("tf_timing_enable", self.handle, mask)
 
     def timing_reset(self):
         self.lib.call("tf_timing_reset", self.handle)

@@ -36,6 +36,10 @@ void stream_sync(Stream* s);
 // one launch: grid (gx, gy, 1), block (block, 1, 1), one by-value argument struct
 void launch(Module* m, int kernel, unsigned gx, unsigned gy, unsigned block,
             const void* args, size_t arg_bytes, Stream* s);
+// same launch; `start` / `stop` receive the kernel's own begin / end timestamps
+// (not the stream-order interval around it)
+void launch_timed(Module* m, int kernel, unsigned gx, unsigned gy, unsigned block,
+                  const void* args, size_t arg_bytes, Stream* s, Event* start, Event* stop);
 
 Event* event_create();
 void event_destroy(Event* e);

@@ -3,6 +3,7 @@
 #include "tf_args.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -111,6 +112,16 @@ void launch(Module* m, int kernel, unsigned gx, unsigned gy, unsigned block,
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<void*>(args),
                       HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
     TF_HIP(hipModuleLaunchKernel(m->fn[kernel], gx, gy, 1, block, 1, 1, 0, s->s, nullptr, config));
+}
+
+void launch_timed(Module* m, int kernel, unsigned gx, unsigned gy, unsigned block,
+                  const void* args, size_t arg_bytes, Stream* s, Event* start, Event* stop) {
+    size_t size = arg_bytes;
+    void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<void*>(args),
+                      HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    // hipExtModuleLaunchKernel takes the global size in work-items
+    TF_HIP(hipExtModuleLaunchKernel(m->fn[kernel], gx * block, gy, 1, block, 1, 1, 0, s->s,
+                                    nullptr, config, start->e, stop->e, 0));
 }
 
 Event* event_create() {

@@ -51,6 +51,18 @@ __global__ void __launch_bounds__(256) tfk_vec_maxabs(TfVecArgs a) {
     }
 }
 
+__global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_berr(TfBerrArgs a) {
+    const double m = tfk_berr_body(a, TF_GID, blockIdx.y);
+    unsigned long long bits = (unsigned long long)__double_as_longlong(m);
+    if (m != m) bits = 0x7ff8000000000000ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(bits, off, 64);
+        bits = o > bits ? o : bits;
+    }
+    if ((threadIdx.x & 63) == 0 && bits != 0) atomicMax((unsigned long long*)a.red, bits);
+}
+
 __global__ void __launch_bounds__(256) tfk_perm(TfPermArgs a) {
     tfk_perm_elem(a, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }

@@ -178,6 +178,61 @@ TF_DEVICE void tfk_spmv_body(const TfSpmvArgs& a, int pg, int seg) {
     }
 }
 
+// componentwise (Oettli-Prager) backward error of (I - cJ) x = b, one pass over J:
+// returns this thread's  max |b - x + cJx| / (|x| + |cJ||x| + |b|)
+TF_DEVICE double tfk_berr_body(const TfBerrArgs& a, int pg, int seg) {
+    const TfLayout& L = a.L;
+    if (pg >= L.Ptot) return 0.0;
+    const int e = pg / L.P, p = pg - e * L.P;
+    const int len = tf_len(L, p);
+    const int i0 = seg * TF_SEG;
+    if (i0 >= len) return 0.0;
+    auto ld = [&](int v, int ii) -> double {
+        const double* plane = a.x + (int64_t)v * L.plane;
+        if (ii >= 0 && ii < len) return plane[tf_idx(L, pg, ii)];
+        return plane[tf_nbr(L, e, p, len, 0, ii)];
+    };
+    double w[TF_NVAR][TF_W];
+#pragma unroll
+    for (int v = 0; v < TF_NVAR; ++v)
+#pragma unroll
+        for (int o = 1; o < TF_W; ++o) w[v][o] = ld(v, i0 - TF_MP + o - 1);
+    double worst = 0.0;
+#pragma unroll
+    for (int j = 0; j < TF_SEG; ++j) {
+        const int i = i0 + j;
+        if (i < len) {
+#pragma unroll
+            for (int v = 0; v < TF_NVAR; ++v) {
+#pragma unroll
+                for (int o = 0; o < TF_W - 1; ++o) w[v][o] = w[v][o + 1];
+                w[v][TF_W - 1] = ld(v, i + TF_MP);
+            }
+            const int64_t s = tf_idx(L, pg, i);
+            double acc[TF_NVAR], mag[TF_NVAR];
+#pragma unroll
+            for (int v = 0; v < TF_NVAR; ++v) { acc[v] = 0.0; mag[v] = 0.0; }
+#pragma unroll
+            for (int k = 0; k < TF_NNZ; ++k) {
+                const double jv = a.c * a.Jv[(int64_t)k * L.plane + s];
+                const double wv = w[tf_pat_var[k]][tf_pat_off[k] + TF_MP];
+                acc[tf_pat_eq[k]] = acc[tf_pat_eq[k]] + jv * wv;
+                mag[tf_pat_eq[k]] = mag[tf_pat_eq[k]] + tf_abs(jv) * tf_abs(wv);
+            }
+#pragma unroll
+            for (int v = 0; v < TF_NVAR; ++v) {
+                const double b = a.rhs[(int64_t)v * L.plane + s];
+                const double xv = w[v][TF_MP];
+                const double num = tf_abs((b - xv) + acc[v]);
+                const double den = tf_abs(xv) + mag[v] + tf_abs(b);
+                const double q = num == 0.0 ? 0.0 : num / den;
+                worst = (q > worst || q != q) ? q : worst;
+            }
+        }
+    }
+    return worst;
+}
+
 // ===========================================================================
 // 3. elementwise plane algebra of the schemes (schemes.py:152-174, 553)
 //    written without contraction, in the association order NumPy uses
@@ -731,16 +786,14 @@ TF_DEVICE void tfk_bt_lu_body(const TfLevelArgs& a, int pg, int dir) {
     const int di = dir > 0 ? 0 : 1;
     bool ok = true;
     double S[BB][BB], Un[BB][BB];
+    double row[3][BB][BB], nxt[3][BB][BB];
+    rows.load(dir > 0 ? 0 : mI - 1, row);
     for (int j = 0; j < mI; ++j) {
         const int i = dir > 0 ? j : mI - 1 - j;
         const int64_t s = tf_idx(L, pg, i);
-        double row[3][BB][BB];
-        rows.load(i, row);
-        if (j == 0) tf_blk_copy<BB>(S, row[1]);
-        else {                                       // S = dia - behind * Un_prev
-            tf_blk_copy<BB>(S, row[1]);
-            tf_mm_sub<BB>(S, row[dir > 0 ? 0 : 2], Un);
-        }
+        if (j + 1 < mI) rows.load(dir > 0 ? j + 1 : mI - 2 - j, nxt);   // next row in flight
+        tf_blk_copy<BB>(S, row[1]);
+        if (j > 0) tf_mm_sub<BB>(S, row[dir > 0 ? 0 : 2], Un);         // S = dia - behind * Un_prev
         double Dinv[BB][BB];
         ok = tf_blk_inverse<BB>(S, Dinv) && ok;
         tf_mm<BB>(Un, Dinv, row[dir > 0 ? 2 : 0]);
@@ -752,6 +805,8 @@ TF_DEVICE void tfk_bt_lu_body(const TfLevelArgs& a, int pg, int dir) {
                 a.Dinv[(int64_t)((di * BB + r) * BB + c) * L.plane + s] = Dinv[r][c];
                 Uout[(int64_t)(r * BB + c) * L.plane + s] = Un[r][c];
             }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) tf_blk_copy<BB>(row[d], nxt[d]);
     }
     // response of the last pivot to the separator ahead
     double* tips = dir > 0 ? a.tips_dn : a.tips_up;
@@ -777,37 +832,53 @@ TF_DEVICE void tfk_bt_col_body(const TfLevelArgs& a, int pg, int dir, int col) {
     double ev[BB], en[BB];
 #pragma unroll
     for (int r = 0; r < BB; ++r) { ev[r] = 0.0; en[r] = 0.0; }
-    for (int j = 0; j < mI; ++j) {
+    // per-node operands, requested one node ahead of their use
+    struct Node { double Lb[BB][BB]; double Di[BB][BB]; double v[BB]; };
+    auto load = [&](int j, Node& n) {
         const int i = dir > 0 ? j : mI - 1 - j;
         const int64_t s = tf_idx(L, pg, i);
-        const int g = start + i;
-        // the backward coupling of this row (absent at a non-periodic system end)
-        const bool has_behind = L.periodic || (dir > 0 ? g > 0 : g < L.N - 1);
-        if (j == 0) {
-            if (is_rhs) {
 #pragma unroll
-                for (int r = 0; r < BB; ++r) ev[r] = a.rhs[(int64_t)r * L.plane + s];
-            } else {
+        for (int r = 0; r < BB; ++r)
 #pragma unroll
-                for (int r = 0; r < BB; ++r)
-                    ev[r] = has_behind ? a.Ablk[(int64_t)((behind * BB + r) * BB + col) * L.plane + s] : 0.0;
+            for (int k = 0; k < BB; ++k) {
+                n.Di[r][k] = a.Dinv[(int64_t)((di * BB + r) * BB + k) * L.plane + s];
+                if (j > 0) n.Lb[r][k] = a.Ablk[(int64_t)((behind * BB + r) * BB + k) * L.plane + s];
             }
+        if (is_rhs) {
+#pragma unroll
+            for (int r = 0; r < BB; ++r) n.v[r] = a.rhs[(int64_t)r * L.plane + s];
+        } else if (j == 0) {
+            // the backward coupling of the first row (absent at a non-periodic system end)
+            const int g = start + i;
+            const bool has_behind = L.periodic || (dir > 0 ? g > 0 : g < L.N - 1);
+#pragma unroll
+            for (int r = 0; r < BB; ++r)
+                n.v[r] = has_behind ? a.Ablk[(int64_t)((behind * BB + r) * BB + col) * L.plane + s] : 0.0;
         } else {
 #pragma unroll
-            for (int r = 0; r < BB; ++r) {
-                double acc = is_rhs ? a.rhs[(int64_t)r * L.plane + s] : 0.0;
+            for (int r = 0; r < BB; ++r) n.v[r] = 0.0;
+        }
+    };
+    Node cur, nxt;
+    load(0, cur);
+    for (int j = 0; j < mI; ++j) {
+        if (j + 1 < mI) load(j + 1, nxt);
+        const int i = dir > 0 ? j : mI - 1 - j;
+        const int64_t s = tf_idx(L, pg, i);
 #pragma unroll
-                for (int k = 0; k < BB; ++k)
-                    acc = tf_fma(-a.Ablk[(int64_t)((behind * BB + r) * BB + k) * L.plane + s], en[k], acc);
-                ev[r] = acc;
+        for (int r = 0; r < BB; ++r) {
+            double acc = cur.v[r];
+            if (j > 0) {
+#pragma unroll
+                for (int k = 0; k < BB; ++k) acc = tf_fma(-cur.Lb[r][k], en[k], acc);
             }
+            ev[r] = acc;
         }
 #pragma unroll
         for (int r = 0; r < BB; ++r) {
             double acc = 0.0;
 #pragma unroll
-            for (int k = 0; k < BB; ++k)
-                acc = tf_fma(a.Dinv[(int64_t)((di * BB + r) * BB + k) * L.plane + s], ev[k], acc);
+            for (int k = 0; k < BB; ++k) acc = tf_fma(cur.Di[r][k], ev[k], acc);
             en[r] = acc;
         }
         if (dir > 0) {
@@ -819,6 +890,7 @@ TF_DEVICE void tfk_bt_col_body(const TfLevelArgs& a, int pg, int dir, int col) {
                 for (int r = 0; r < BB; ++r) a.Et[(int64_t)(r * BB + col) * L.plane + s] = en[r];
             }
         }
+        cur = nxt;
     }
     double* tips = dir > 0 ? a.tips_dn : a.tips_up;
 #pragma unroll
@@ -957,23 +1029,35 @@ TF_DEVICE void tfk_backsub_body(const TfLevelArgs& a, int pg) {
 #pragma unroll
         for (int r = 0; r < B; ++r) a.x[(int64_t)r * L.plane + s] = xn[t][r];
     }
-    for (int j = mI - 1; j >= 0; --j) {
+    // the factors of node j-1 are requested before node j is processed, so one
+    // HBM latency is paid per chunk, not per node
+    struct Node { double y[B]; double U[MP][B][B]; double E[MP][B][B]; };
+    auto load = [&](int j, Node& n) {
         const int64_t s = tf_idx(L, pg, j);
-        double x[B];
 #pragma unroll
-        for (int r = 0; r < B; ++r) x[r] = a.yt[(int64_t)r * L.plane + s];
+        for (int r = 0; r < B; ++r) n.y[r] = a.yt[(int64_t)r * L.plane + s];
 #pragma unroll
-        for (int c = 0; c < MP; ++c) {
-            double Ub[B][B], Eb[B][B];
+        for (int c = 0; c < MP; ++c)
 #pragma unroll
             for (int r = 0; r < B; ++r)
 #pragma unroll
                 for (int k = 0; k < B; ++k) {
-                    Ub[r][k] = a.Ut[(int64_t)((c * B + r) * B + k) * L.plane + s];
-                    Eb[r][k] = a.Et[(int64_t)((c * B + r) * B + k) * L.plane + s];
+                    n.U[c][r][k] = a.Ut[(int64_t)((c * B + r) * B + k) * L.plane + s];
+                    n.E[c][r][k] = a.Et[(int64_t)((c * B + r) * B + k) * L.plane + s];
                 }
-            tf_mv_sub<B>(x, Ub, xn[c]);
-            tf_mv_sub<B>(x, Eb, sa[c]);
+    };
+    Node cur, nxt;
+    load(mI - 1, cur);
+    for (int j = mI - 1; j >= 0; --j) {
+        if (j > 0) load(j - 1, nxt);
+        const int64_t s = tf_idx(L, pg, j);
+        double x[B];
+#pragma unroll
+        for (int r = 0; r < B; ++r) x[r] = cur.y[r];
+#pragma unroll
+        for (int c = 0; c < MP; ++c) {
+            tf_mv_sub<B>(x, cur.U[c], xn[c]);
+            tf_mv_sub<B>(x, cur.E[c], sa[c]);
         }
 #pragma unroll
         for (int c = MP - 1; c > 0; --c)
@@ -981,6 +1065,7 @@ TF_DEVICE void tfk_backsub_body(const TfLevelArgs& a, int pg) {
             for (int r = 0; r < B; ++r) xn[c][r] = xn[c - 1][r];
 #pragma unroll
         for (int r = 0; r < B; ++r) { xn[0][r] = x[r]; a.x[(int64_t)r * L.plane + s] = x[r]; }
+        cur = nxt;
     }
 }
 

@@ -116,7 +116,7 @@ struct tf_solver {
     double bdf_dt_prev = 0.0;
 
     // timing
-    bool timing = false;
+    uint32_t timing = 0;     // bit k: time launches of kernel k
     struct Stamp { int kernel; tfb::Event *a, *b; };
     std::vector<Stamp> stamps;
     std::vector<tfb::Event*> event_pool;
@@ -145,11 +145,9 @@ struct tf_solver {
         return tfb::event_create();
     }
     void launch(int kernel, unsigned gx, unsigned gy, unsigned block, const void* args, size_t sz) {
-        if (timing) {
+        if ((timing >> kernel) & 1u) {
             Stamp stp{kernel, get_event(), get_event()};
-            tfb::event_record(stp.a, stream);
-            tfb::launch(model->module, kernel, gx, gy, block, args, sz, stream);
-            tfb::event_record(stp.b, stream);
+            tfb::launch_timed(model->module, kernel, gx, gy, block, args, sz, stream, stp.a, stp.b);
             stamps.push_back(stp);
         } else {
             tfb::launch(model->module, kernel, gx, gy, block, args, sz, stream);
@@ -299,13 +297,11 @@ struct tf_solver {
     // componentwise (Oettli-Prager) backward error
     //   max_i |b - A x|_i / (|x| + |c J||x| + |b|)_i
     double backward_error(const double* rhs1, const double* x1) {
-        spmv(x1, Wjv.p, factor_c);
-        const double* xs[3] = {rhs1, x1, Wjv.p};
-        vec(TF_VEC_RESID, Wres.p, nullptr, 3, xs, nullptr);
-        spmv(x1, Wjv.p, factor_c, true);
         tfb::memset0(red.p, sizeof(double), stream);
-        const double* q[4] = {Wres.p, x1, Wjv.p, rhs1};
-        vec(TF_VEC_MAXRATIO, nullptr, nullptr, 4, q, nullptr);
+        TfBerrArgs a;
+        a.L = L1; a.Jv = Jv.p; a.x = x1; a.rhs = rhs1; a.c = factor_c; a.red = red.p;
+        unsigned gx = cdiv(L1.Ptot, spec.sweep_block), gy = cdiv(L1.M, spec.seg);
+        launch(TFK_BERR, gx, gy, spec.sweep_block, &a, sizeof(a));
         double h = 0;
         tfb::d2h(&h, red.p, sizeof(h), stream);
         return h;
@@ -771,7 +767,7 @@ int tf_timing_enable(tf_solver* s, int32_t on) {
     TF_API_BEGIN
     require(s, "null solver");
     s->collect_timing();
-    s->timing = on != 0;
+    s->timing = on < 0 ? 0xffffffffu : (uint32_t)on;
     TF_API_END
 }
 int tf_timing_reset(tf_solver* s) {
