@@ -19,8 +19,10 @@ There is no CPU implementation behind this module: without ``hipcc`` or the
 built ``libtriflow_hip.so`` it raises.
 """
 
+import json
 import logging
 import os
+import re
 import shutil
 import subprocess
 import threading
@@ -83,6 +85,30 @@ def build_runtime_library(force=False):
     return LIB_PATH
 
 
+def _parse_resource_usage(stderr):
+    """{kernel: {VGPRs, SGPRs, ScratchSize, Occupancy}} from -Rpass-analysis output."""
+    usage, name = {}, None
+    for line in stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            usage[name] = {}
+            continue
+        for key, pat in (("VGPRs", r" VGPRs: (\d+)"), ("SGPRs", r" SGPRs: (\d+)"),
+                         ("ScratchSize", r"ScratchSize \[bytes/lane\]: (\d+)"),
+                         ("Occupancy", r"Occupancy \[waves/SIMD\]: (\d+)")):
+            m = re.search(pat, line)
+            if m and name:
+                usage[name][key] = int(m.group(1))
+    return usage
+
+
+def resource_usage(hsaco_path):
+    """Resource table written next to a cached code object."""
+    with open(hsaco_path[:-len(".hsaco")] + ".json") as f:
+        return json.load(f)["kernels"]
+
+
 def build_code_object(model, parvec_mask=0, seg=None, sweep_block=None):
     """Model -> (path of the cached gfx950 code object, spec dict)."""
     seg = seg or int(os.environ.get("TRIFLOW_SWEEP_SEG", "8"))
@@ -99,12 +125,21 @@ def build_code_object(model, parvec_mask=0, seg=None, sweep_block=None):
             f.write(source)
         tmp = hsaco + ".%d.tmp" % os.getpid()
         cmd = [_hipcc(), *HIPCC_FLAGS, "-I", CSRC, "--genco", "--no-gpu-bundle-output",
-               "-o", tmp, hip]
+               "-Rpass-analysis=kernel-resource-usage", "-o", tmp, hip]
         log.info("hipcc: compiling stencil + solver kernels for %s", model._diff_eqs)
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError("hipcc failed on the generated kernels (%s):\n%s"
                                % (hip, res.stderr[-4000:]))
+        usage = _parse_resource_usage(res.stderr)
+        with open(os.path.join(CACHE_DIR, "model_%s.json" % tag), "w") as f:
+            json.dump(dict(equations=list(model._diff_eqs), flags=HIPCC_FLAGS, kernels=usage),
+                      f, indent=1)
+        spilled = [k for k, u in usage.items() if u.get("ScratchSize", 0) > 0]
+        if spilled:
+            # register spills: slow, and hipcc 7.2 was seen to miscompile a spilling
+            # solver kernel at -O2/-O3 ("compiler notes")
+            log.warning("kernels with scratch spills for %s: %s", model._diff_eqs, spilled)
         os.replace(tmp, hsaco)
     return hsaco, spec
 

@@ -786,12 +786,11 @@ TF_DEVICE void tfk_bt_lu_body(const TfLevelArgs& a, int pg, int dir) {
     const int di = dir > 0 ? 0 : 1;
     bool ok = true;
     double S[BB][BB], Un[BB][BB];
-    double row[3][BB][BB], nxt[3][BB][BB];
-    rows.load(dir > 0 ? 0 : mI - 1, row);
     for (int j = 0; j < mI; ++j) {
         const int i = dir > 0 ? j : mI - 1 - j;
         const int64_t s = tf_idx(L, pg, i);
-        if (j + 1 < mI) rows.load(dir > 0 ? j + 1 : mI - 2 - j, nxt);   // next row in flight
+        double row[3][BB][BB];
+        rows.load(i, row);
         tf_blk_copy<BB>(S, row[1]);
         if (j > 0) tf_mm_sub<BB>(S, row[dir > 0 ? 0 : 2], Un);         // S = dia - behind * Un_prev
         double Dinv[BB][BB];
@@ -805,8 +804,6 @@ TF_DEVICE void tfk_bt_lu_body(const TfLevelArgs& a, int pg, int dir) {
                 a.Dinv[(int64_t)((di * BB + r) * BB + c) * L.plane + s] = Dinv[r][c];
                 Uout[(int64_t)(r * BB + c) * L.plane + s] = Un[r][c];
             }
-#pragma unroll
-        for (int d = 0; d < 3; ++d) tf_blk_copy<BB>(row[d], nxt[d]);
     }
     // response of the last pivot to the separator ahead
     double* tips = dir > 0 ? a.tips_dn : a.tips_up;
