@@ -92,6 +92,8 @@ int tf_set_dirichlet(tf_solver*, int32_t n, const int32_t* var, const int64_t* n
 
 /* ---- seam #1: F / J evaluation on the resident state ----------------------- */
 int tf_eval(tf_solver*, int32_t slot, int32_t with_j);
+/* `reps` back-to-back sweeps between two HIP events on the solver's stream */
+int tf_eval_repeat(tf_solver*, int32_t slot, int32_t with_j, int32_t reps, double* total_ms);
 int tf_get_F(tf_solver*, double* F /*[nsys][N*nvar], F[node*nvar+eq]*/);
 int tf_get_J(tf_solver*, double* Jvals /*[nsys][N][nnz], reference pattern order*/);
 

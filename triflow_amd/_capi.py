@@ -49,6 +49,7 @@ SIGNATURES = {
     "tf_set_x": (C.c_int, [C.c_void_p, c_double_p]),
     "tf_set_dirichlet": (C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int64_p, c_double_p]),
     "tf_eval": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "tf_eval_repeat": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_double_p]),
     "tf_get_F": (C.c_int, [C.c_void_p, c_double_p]),
     "tf_get_J": (C.c_int, [C.c_void_p, c_double_p]),
     "tf_factor": (C.c_int, [C.c_void_p, C.c_double]),
@@ -232,6 +233,12 @@ class DeviceSolver:
     # ----------------------------------------------------------------- seam #1
     def eval(self, slot=0, with_j=False):
         self.lib.call("tf_eval", self.handle, slot, int(with_j))
+
+    def eval_repeat(self, slot=0, with_j=True, reps=20):
+        """Mean duration (ms) of ``reps`` back-to-back sweeps (two HIP events)."""
+        ms = C.c_double(0.0)
+        self.lib.call("tf_eval_repeat", self.handle, slot, int(with_j), reps, C.byref(ms))
+        return ms.value / reps
 
     def get_F(self):
         out = np.empty((self.nsys, self.N * self.nvar))

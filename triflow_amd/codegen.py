@@ -43,8 +43,36 @@ def _dbl(value):
 
 
 class _CEmitter(ast.NodeVisitor):
-    def __init__(self, names):
+    """Python expression AST -> C expression string.  Also tracks which
+    sub-expressions are *uniform* (same value for every node a thread visits:
+    dx, scalar parameters, constants) so that divisions by a uniform divisor can
+    use the exact reciprocal form ``tf_div_u`` with the divisor and its
+    reciprocal hoisted out of the node loop."""
+
+    def __init__(self, names, uniform_names=()):
         self.names = names          # python identifier -> C expression
+        self.uniform_names = set(uniform_names)
+        self.denominators = {}      # C expression -> index
+        self.den_count = {}         # C expression -> number of quotients using it
+        self.shared = {}            # den_count of a previous pass over the same expressions
+
+    def is_uniform(self, node):
+        if isinstance(node, ast.Constant):
+            return True
+        if isinstance(node, ast.Name):
+            return node.id in self.uniform_names or node.id in ("pi", "E")
+        if isinstance(node, ast.UnaryOp):
+            return self.is_uniform(node.operand)
+        if isinstance(node, ast.BinOp):
+            return self.is_uniform(node.left) and self.is_uniform(node.right)
+        if isinstance(node, ast.Call):
+            args = []
+            for a in node.args:
+                args.extend(a.elts if isinstance(a, (ast.List, ast.Tuple)) else [a])
+            return all(self.is_uniform(a) for a in args
+                       if not isinstance(a, (ast.Name, ast.Attribute)) or
+                       not (getattr(a, "id", getattr(a, "attr", "")) in ("maximum", "minimum")))
+        return False
 
     def visit_Name(self, node):
         if node.id in self.names:
@@ -71,6 +99,15 @@ class _CEmitter(ast.NodeVisitor):
     def visit_BinOp(self, node):
         if isinstance(node.op, ast.Pow):
             return self._pow(node)
+        if isinstance(node.op, ast.Div) and not self.is_uniform(node.left):
+            den = self.visit(node.right)
+            self.den_count[den] = self.den_count.get(den, 0) + 1
+            # uniform divisor: reciprocal hoisted out of the node loop; a
+            # node-dependent divisor shared by several quotients of the same node:
+            # one true division for the reciprocal, then the exact 3-op quotient
+            if self.is_uniform(node.right) or self.shared.get(den, 0) >= 2:
+                k = self.denominators.setdefault(den, len(self.denominators))
+                return "tf_div_u(%s, tf_den%d, tf_rden%d)" % (self.visit(node.left), k, k)
         ops = {ast.Add: "+", ast.Sub: "-", ast.Mult: "*", ast.Div: "/"}
         for klass, sym in ops.items():
             if isinstance(node.op, klass):
@@ -188,16 +225,28 @@ def lower_model(model, parvec_mask=0, seg=8, sweep_block=64):
     names["dx"] = "dx"
     names["x"] = "xc"
 
-    emit = _CEmitter(names)
+    uniform = {"dx"} | {name for k, name in enumerate(pars) if not (parvec_mask >> k) & 1}
     f_nodes = _printed_expressions(model._symbolic_args, model.F_array.tolist())
     j_nodes = _printed_expressions(model._symbolic_args, model._J_sparse_array.tolist())
-    f_c = [emit.visit(n) for n in f_nodes]
-    j_c = [emit.visit(n) for n in j_nodes]
+    def emit_all(nodes):
+        first = _CEmitter(names, uniform)           # pass 1: count divisor reuse
+        for n in nodes:
+            first.visit(n)
+        second = _CEmitter(names, uniform)
+        second.shared = first.den_count
+        return second, [second.visit(n) for n in nodes]
+
+    emit_f, f_c = emit_all(f_nodes)
+    emit_j, j_c = emit_all(j_nodes)
     uses_x = any("xc" in _tokens(s) for s in f_c + j_c)
 
-    def body(outname, exprs):
+    def body(outname, exprs, emitter):
         lines = ["    " + d for d in decls]
         lines += ["    (void)dx; (void)xc; (void)par;"]
+        # node-independent divisors and their reciprocals: loop invariant, hoisted
+        for den, k in sorted(emitter.denominators.items(), key=lambda kv: kv[1]):
+            lines += ["    const double tf_den%d = %s;" % (k, den),
+                      "    const double tf_rden%d = 1.0 / tf_den%d;" % (k, k)]
         lines += ["    %s[%d] = %s;" % (outname, i, e) for i, e in enumerate(exprs)]
         return "\n".join(lines)
 
@@ -221,11 +270,11 @@ def lower_model(model, parvec_mask=0, seg=8, sweep_block=64):
         arr("tf_par_is_vec", par_is_vec, "bool"),
         "TF_DEVICE void tf_eval_F(const double (&w)[TF_NVAR + TF_NH][2 * TF_MP + 1], "
         "const double* par, double dx, double xc, double* F) {",
-        body("F", f_c),
+        body("F", f_c, emit_f),
         "}",
         "TF_DEVICE void tf_eval_J(const double (&w)[TF_NVAR + TF_NH][2 * TF_MP + 1], "
         "const double* par, double dx, double xc, double* J) {",
-        body("J", j_c),
+        body("J", j_c, emit_j),
         "}",
         ""])
     spec = dict(nvar=nvar, nh=nh, npar=len(pars), mp=mp, nnz=nnz, seg=seg,

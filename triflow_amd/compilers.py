@@ -47,7 +47,10 @@ HIPCC_FLAGS = [*os.environ.get("TRIFLOW_HIPCC_OPT", "-O3").split(), "-std=c++17"
 _SKELETON = ("tf_args.h", "tf_math.h", "tf_kernels.h", "tf_entry_hip.h")
 _TU_HEAD = ('#include <hip/hip_runtime.h>\n'
             '#define TF_DEVICE __device__ __forceinline__\n'
+            '%s'
             '#include "tf_math.h"\n')
+_NT_STORE = '#define TF_STORE_STREAM(ptr, val) __builtin_nontemporal_store((val), (ptr))\n'
+
 _TU_TAIL = '#include "tf_kernels.h"\n#include "tf_entry_hip.h"\n'
 
 
@@ -115,7 +118,8 @@ def build_code_object(model, parvec_mask=0, seg=None, sweep_block=None):
     sweep_block = sweep_block or int(os.environ.get("TRIFLOW_SWEEP_BLOCK", "64"))
     body, spec = codegen.lower_model(model, parvec_mask=parvec_mask, seg=seg,
                                      sweep_block=sweep_block)
-    source = _TU_HEAD + body + _TU_TAIL
+    nt = int(os.environ.get("TRIFLOW_SWEEP_NT", "0"))
+    source = _TU_HEAD % (_NT_STORE if nt else "") + body + _TU_TAIL
     tag = codegen.source_hash(source, _skeleton_stamp(), " ".join(HIPCC_FLAGS), "elf")
     os.makedirs(CACHE_DIR, exist_ok=True)
     hsaco = os.path.join(CACHE_DIR, "model_%s.hsaco" % tag)

@@ -119,12 +119,12 @@ TF_DEVICE void tfk_sweep_body(const TfSweepArgs& a, int pg, int seg) {
             double Fo[TF_NVAR];
             tf_eval_F(w, par, dx, xc, Fo);
 #pragma unroll
-            for (int v = 0; v < TF_NVAR; ++v) a.F[(int64_t)v * L.plane + s] = Fo[v];
+            for (int v = 0; v < TF_NVAR; ++v) TF_STORE_STREAM(&a.F[(int64_t)v * L.plane + s], Fo[v]);
             if (WITH_J) {
                 double Jo[TF_NNZ > 0 ? TF_NNZ : 1];
                 tf_eval_J(w, par, dx, xc, Jo);
 #pragma unroll
-                for (int k = 0; k < TF_NNZ; ++k) a.Jv[(int64_t)k * L.plane + s] = Jo[k];
+                for (int k = 0; k < TF_NNZ; ++k) TF_STORE_STREAM(&a.Jv[(int64_t)k * L.plane + s], Jo[k]);
             }
         }
     }

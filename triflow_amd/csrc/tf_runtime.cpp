@@ -573,6 +573,23 @@ int tf_eval(tf_solver* s, int32_t slot, int32_t with_j) {
     s->sweep(s->st(slot), with_j != 0);
     TF_API_END
 }
+int tf_eval_repeat(tf_solver* s, int32_t slot, int32_t with_j, int32_t reps, double* total_ms) {
+    TF_API_BEGIN
+    require(s && total_ms && reps >= 1, "tf_eval_repeat: arguments");
+    const uint32_t saved = s->timing;
+    s->timing = 0;
+    tfb::Event* a = s->get_event();
+    tfb::Event* b = s->get_event();
+    tfb::event_record(a, s->stream);
+    for (int i = 0; i < reps; ++i) s->sweep(s->st(slot), with_j != 0);
+    tfb::event_record(b, s->stream);
+    tfb::stream_sync(s->stream);
+    *total_ms = tfb::event_elapsed_ms(a, b);
+    s->event_pool.push_back(a);
+    s->event_pool.push_back(b);
+    s->timing = saved;
+    TF_API_END
+}
 int tf_get_F(tf_solver* s, double* Fh) {
     TF_API_BEGIN
     require(s && Fh, "null argument");
