@@ -55,8 +55,11 @@ typedef struct tf_solver_opts {
     int32_t nstate;       /* resident state slots                   (0 = default 3) */
     int32_t refine;       /* refinement sweeps per solve; 0 = none, -1 = automatic:
                              measure the backward error of the first solve after
-                             each factorisation and polish only if it is > 1e-12   */
+                             each factorisation and polish only if it is > 1e-10   */
     int32_t device;       /* HIP device ordinal (-1 = current)                      */
+    int32_t tail_chunks;  /* reduced levels with at most this many chunks run fused in
+                             one single-workgroup launch (0 = off, the default: measured
+                             no faster than separate launches on MI355X)            */
 } tf_solver_opts;
 
 const char* tf_last_error(void);

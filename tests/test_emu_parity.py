@@ -34,7 +34,7 @@ def test_FJ_ragged_chunks(name, N, backend):
 @pytest.mark.parametrize("name", ["M2_diff", "M3_film", "M5_stiff", "kuramoto"])
 def test_linear_solve(name, backend):
     plans = [dict(m1=4, m_upper=2), dict(m1=7, m_upper=3), dict(m1=32, m_upper=8),
-             dict(m1=10 ** 6)]
+             dict(m1=10 ** 6), dict(m1=4, m_upper=2, tail_chunks=16)]
     pc.check_linear_solve(name, backend, 203, plans, tol=1e-9)
 
 

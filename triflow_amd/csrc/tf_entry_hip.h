@@ -102,4 +102,10 @@ __global__ void __launch_bounds__(64) tfk_bt_backsub(TfLevelArgs a) { tfk_backsu
 __global__ void __launch_bounds__(64) tfk_top_factor(TfTopArgs a) { tfk_top_body<TF_B2, true>(a, TF_GID); }
 __global__ void __launch_bounds__(64) tfk_top_solve(TfTopArgs a) { tfk_top_body<TF_B2, false>(a, TF_GID); }
 
+// one workgroup of 256 threads; phases separated by workgroup barriers (the data
+// handed from phase to phase stays on this CU: same L1, L2 write-through)
+__global__ void __launch_bounds__(256) tfk_tail(TfTailArgs a) {
+    tfk_tail_body<TF_B2>(a, threadIdx.x, blockDim.x, [] { __threadfence_block(); __syncthreads(); });
+}
+
 }  // extern "C"

@@ -1097,3 +1097,43 @@ TF_DEVICE void tfk_top_body(const TfTopArgs& a, int e) {
         for (int r = 0; r < BB; ++r) a.x[(int64_t)r * a.nsys + e] = x[r];
     }
 }
+
+// ---- fused tail: all phases of the smallest levels + top in one workgroup -----
+// `sync()` separates phases (workgroup barrier on the device, nothing in the
+// single-threaded host build); thread `tid` of `nthreads` strides over the work
+// items of each phase.
+template <int BB, class Sync>
+TF_DEVICE void tfk_tail_body(const TfTailArgs& a, int tid, int nthreads, Sync sync) {
+    typedef TfRowsBT<BB> Rows;
+    for (int l = 0; l < a.nlv; ++l) {
+        const TfLevelArgs& lv = a.lv[l];
+        const int np = lv.L.Ptot;
+        if (a.factor) {
+            for (int t = tid; t < 2 * np; t += nthreads) tfk_bt_lu_body<BB>(lv, t % np, t < np ? +1 : -1);
+            sync();
+            for (int t = tid; t < 2 * BB * np; t += nthreads) {
+                const int y = t / np;
+                tfk_bt_col_body<BB>(lv, t % np, (y & 1) == 0 ? +1 : -1, y >> 1);
+            }
+            sync();
+            for (int t = tid; t < np; t += nthreads) tfk_asm_body<Rows, true>(lv, t);
+            sync();
+        } else {
+            for (int t = tid; t < 2 * np; t += nthreads) tfk_bt_col_body<BB>(lv, t % np, t < np ? +1 : -1, BB);
+            sync();
+            for (int t = tid; t < np; t += nthreads) tfk_asm_body<Rows, false>(lv, t);
+            sync();
+        }
+    }
+    if (a.factor) {
+        for (int t = tid; t < a.top.nsys; t += nthreads) tfk_top_body<BB, true>(a.top, t);
+    } else {
+        for (int t = tid; t < a.top.nsys; t += nthreads) tfk_top_body<BB, false>(a.top, t);
+        sync();
+        for (int l = a.nlv - 1; l >= 0; --l) {
+            const TfLevelArgs& lv = a.lv[l];
+            for (int t = tid; t < lv.L.Ptot; t += nthreads) tfk_backsub_body<Rows>(lv, t);
+            sync();
+        }
+    }
+}

@@ -104,7 +104,7 @@ struct tf_solver {
     double factor_c = 0.0;
     bool have_factor = false, have_jac = false;
     bool fact_checked = false, fact_needs_refine = false;   // refine == -1 (auto)
-    double last_omega = 0.0, refine_trigger = 1e-12;
+    double last_omega = 0.0, refine_trigger = 1e-10;
 
     // declarative Dirichlet hook
     int ndir = 0;
@@ -250,10 +250,29 @@ struct tf_solver {
         a.status = status;
         return a;
     }
+    // first level handled by the fused single-workgroup tail (levels.size() = none)
+    size_t tail_from = 0;
+    TfTopArgs top_args() {
+        TfTopArgs t;
+        t.nsys = nsys; t.A = top.Ablk.p; t.rhs = top.rhs.p; t.Ainv = topAinv.p; t.x = top.x.p; t.status = status;
+        return t;
+    }
+    void launch_tail(bool is_factor, const double* rhs1, double* x1) {
+        TfTailArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.nlv = (int)(levels.size() - tail_from);
+        a.factor = is_factor ? 1 : 0;
+        for (size_t l = tail_from; l < levels.size(); ++l) {
+            a.lv[l - tail_from] = level_args(l, rhs1, x1);
+            if (is_factor) a.lv[l - tail_from].rhs = nullptr;
+        }
+        a.top = top_args();
+        launch(TFK_TAIL, 1, 1, 256, &a, sizeof(a));
+    }
     void factor(double c) {
         if (!have_jac) throw std::runtime_error("tf_factor: no Jacobian evaluated yet (call tf_eval with_j=1)");
         factor_c = c;
-        for (size_t l = 0; l < levels.size(); ++l) {
+        for (size_t l = 0; l < tail_from; ++l) {
             TfLevelArgs a = level_args(l, nullptr, nullptr);
             a.rhs = nullptr;
             unsigned gx = cdiv(a.L.Ptot, 64);
@@ -264,24 +283,22 @@ struct tf_solver {
             }
             launch(l == 0 ? TFK_L1_ASM_MAT : TFK_BT_ASM_MAT, gx, 1, 64, &a, sizeof(a));
         }
-        TfTopArgs t;
-        t.nsys = nsys; t.A = top.Ablk.p; t.rhs = top.rhs.p; t.Ainv = topAinv.p; t.x = top.x.p; t.status = status;
-        launch(TFK_TOP_FACTOR, cdiv(nsys, 64), 1, 64, &t, sizeof(t));
+        if (tail_from < levels.size()) launch_tail(true, nullptr, nullptr);
+        else { TfTopArgs t = top_args(); launch(TFK_TOP_FACTOR, cdiv(nsys, 64), 1, 64, &t, sizeof(t)); }
         have_factor = true;
         fact_checked = false;
         fact_needs_refine = false;
     }
     void solve_once(const double* rhs1, double* x1) {
-        for (size_t l = 0; l < levels.size(); ++l) {
+        for (size_t l = 0; l < tail_from; ++l) {
             TfLevelArgs a = level_args(l, rhs1, x1);
             unsigned gx = cdiv(a.L.Ptot, 64);
             launch(l == 0 ? TFK_L1_SOLVE : TFK_BT_RHS, gx, 2, 64, &a, sizeof(a));
             launch(l == 0 ? TFK_L1_ASM_RHS : TFK_BT_ASM_RHS, gx, 1, 64, &a, sizeof(a));
         }
-        TfTopArgs t;
-        t.nsys = nsys; t.A = top.Ablk.p; t.rhs = top.rhs.p; t.Ainv = topAinv.p; t.x = top.x.p; t.status = status;
-        launch(TFK_TOP_SOLVE, cdiv(nsys, 64), 1, 64, &t, sizeof(t));
-        for (size_t l = levels.size(); l-- > 0;) {
+        if (tail_from < levels.size()) launch_tail(false, rhs1, x1);
+        else { TfTopArgs t = top_args(); launch(TFK_TOP_SOLVE, cdiv(nsys, 64), 1, 64, &t, sizeof(t)); }
+        for (size_t l = tail_from; l-- > 0;) {
             TfLevelArgs a = level_args(l, rhs1, x1);
             launch(l == 0 ? TFK_L1_BACKSUB : TFK_BT_BACKSUB, cdiv(a.L.Ptot, 64), 1, 64, &a, sizeof(a));
         }
@@ -404,6 +421,12 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
         }
         s->top.L = make_layout(nsys, 1, 1, s->periodic);
         s->top.B = b2; s->top.MP = 1;
+    }
+    {
+        const int tail_chunks = opts && opts->tail_chunks > 0 ? opts->tail_chunks : 0;
+        s->tail_from = s->levels.size();
+        for (size_t l = 1; l < s->levels.size(); ++l)
+            if (s->levels[l]->L.Ptot <= tail_chunks && s->levels.size() - l <= TF_MAX_TAIL) { s->tail_from = l; break; }
     }
     s->L1 = s->levels[0]->L;
     const int64_t plane = s->L1.plane;
