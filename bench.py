@@ -95,12 +95,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    # rehearsal on a one-GPU box: TRIFLOW_BENCH_BACKEND=gloo puts every rank on GPU 0
+    backend = os.environ.get("TRIFLOW_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else 0
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(device_index)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from oracle import corpus
     from triflow_amd import Model
@@ -116,7 +122,7 @@ def main():
     N = x.size
     model = Model(*corpus.model_args(name))
     ens = Ensemble(model, x, fields, pars, bool(pars["periodic"]), scheme=scheme,
-                   device=local_rank, hook=None, nstate=2)
+                   device=device_index, hook=None, nstate=2)
     solver = ens.solver
 
     def barrier():
@@ -148,7 +154,8 @@ def main():
     report = solver.timing_report()
     solver.timing(False)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64,
+                            device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     state = ens.state()

@@ -28,6 +28,7 @@ struct Stream { int dummy; };
 struct Event { int dummy; };
 
 bool is_device_build() { return false; }
+int coop_group(int) { return 1; }
 int device_count() { return 0; }
 void set_device(int) {}
 void* dev_alloc(size_t bytes) { void* p = std::calloc(bytes ? bytes : 8, 1); if (!p) throw std::bad_alloc(); return p; }

@@ -16,6 +16,8 @@ struct Stream;
 struct Event;
 
 bool is_device_build();
+// lanes that share one chunk in the reduced-level kernels of block size b
+int coop_group(int b);
 int device_count();
 void set_device(int ordinal);                 // throws std::runtime_error
 

@@ -23,6 +23,7 @@ struct Stream { hipStream_t s; };
 struct Event { hipEvent_t e; };
 
 bool is_device_build() { return true; }
+int coop_group(int b) { return b <= 2 ? 1 : (b <= 8 ? 8 : (b <= 16 ? 16 : 1)); }   // TfCoop<b>::G
 
 int device_count() {
     int n = 0;

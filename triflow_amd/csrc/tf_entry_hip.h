@@ -4,6 +4,8 @@
 // hipModuleGetFunction.
 #pragma once
 
+#include "tf_coop_hip.h"
+
 #define TF_GID ((int)(blockIdx.x * blockDim.x + threadIdx.x))
 
 extern "C" {
@@ -86,19 +88,28 @@ __global__ void __launch_bounds__(64) tfk_l1_backsub(TfLevelArgs a) { tfk_backsu
 
 // ---- banded solver, levels >= 2 (explicit block-tridiagonal rows) -----------
 typedef TfRowsBT<TF_B2> TfRowsUp;
+// Wave-cooperative for b > 2 (tf_coop_hip.h: TfCoop<b>::G lanes per chunk, the host
+// multiplies the thread count accordingly), one thread per chunk otherwise.
 // grid.y: 0 = walk down, 1 = walk up; tfk_bt_spike: grid.y = 2 * b (direction, column)
 __global__ void __launch_bounds__(64) tfk_bt_lu(TfLevelArgs a) {
-    tfk_bt_lu_body<TF_B2>(a, TF_GID, blockIdx.y == 0 ? +1 : -1);
+    if constexpr (TfCoop<TF_B2>::G > 1) tfk_bt_lu_coop<TF_B2>(a, blockIdx.y == 0 ? +1 : -1);
+    else tfk_bt_lu_body<TF_B2>(a, TF_GID, blockIdx.y == 0 ? +1 : -1);
 }
 __global__ void __launch_bounds__(64) tfk_bt_spike(TfLevelArgs a) {
-    tfk_bt_col_body<TF_B2>(a, TF_GID, (blockIdx.y & 1) == 0 ? +1 : -1, blockIdx.y >> 1);
+    if constexpr (TfCoop<TF_B2>::G > 1)
+        tfk_bt_col_coop<TF_B2>(a, (blockIdx.y & 1) == 0 ? +1 : -1, blockIdx.y >> 1);
+    else tfk_bt_col_body<TF_B2>(a, TF_GID, (blockIdx.y & 1) == 0 ? +1 : -1, blockIdx.y >> 1);
 }
 __global__ void __launch_bounds__(64) tfk_bt_rhs(TfLevelArgs a) {
-    tfk_bt_col_body<TF_B2>(a, TF_GID, blockIdx.y == 0 ? +1 : -1, TF_B2);
+    if constexpr (TfCoop<TF_B2>::G > 1) tfk_bt_col_coop<TF_B2>(a, blockIdx.y == 0 ? +1 : -1, TF_B2);
+    else tfk_bt_col_body<TF_B2>(a, TF_GID, blockIdx.y == 0 ? +1 : -1, TF_B2);
 }
 __global__ void __launch_bounds__(64) tfk_bt_asm_mat(TfLevelArgs a) { tfk_asm_body<TfRowsUp, true>(a, TF_GID); }
 __global__ void __launch_bounds__(64) tfk_bt_asm_rhs(TfLevelArgs a) { tfk_asm_body<TfRowsUp, false>(a, TF_GID); }
-__global__ void __launch_bounds__(64) tfk_bt_backsub(TfLevelArgs a) { tfk_backsub_body<TfRowsUp>(a, TF_GID); }
+__global__ void __launch_bounds__(64) tfk_bt_backsub(TfLevelArgs a) {
+    if constexpr (TfCoop<TF_B2>::G > 1) tfk_bt_backsub_coop<TF_B2>(a);
+    else tfk_backsub_body<TfRowsUp>(a, TF_GID);
+}
 __global__ void __launch_bounds__(64) tfk_top_factor(TfTopArgs a) { tfk_top_body<TF_B2, true>(a, TF_GID); }
 __global__ void __launch_bounds__(64) tfk_top_solve(TfTopArgs a) { tfk_top_body<TF_B2, false>(a, TF_GID); }
 

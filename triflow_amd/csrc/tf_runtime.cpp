@@ -278,8 +278,9 @@ struct tf_solver {
             unsigned gx = cdiv(a.L.Ptot, 64);
             if (l == 0) launch(TFK_L1_FACTOR, gx, 2, 64, &a, sizeof(a));
             else {
-                launch(TFK_BT_LU, gx, 2, 64, &a, sizeof(a));
-                launch(TFK_BT_SPIKE, gx, 2 * (unsigned)levels[l]->B, 64, &a, sizeof(a));
+                const unsigned gc = cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64);
+                launch(TFK_BT_LU, gc, 2, 64, &a, sizeof(a));
+                launch(TFK_BT_SPIKE, gc, 2 * (unsigned)levels[l]->B, 64, &a, sizeof(a));
             }
             launch(l == 0 ? TFK_L1_ASM_MAT : TFK_BT_ASM_MAT, gx, 1, 64, &a, sizeof(a));
         }
@@ -293,14 +294,16 @@ struct tf_solver {
         for (size_t l = 0; l < tail_from; ++l) {
             TfLevelArgs a = level_args(l, rhs1, x1);
             unsigned gx = cdiv(a.L.Ptot, 64);
-            launch(l == 0 ? TFK_L1_SOLVE : TFK_BT_RHS, gx, 2, 64, &a, sizeof(a));
+            if (l == 0) launch(TFK_L1_SOLVE, gx, 2, 64, &a, sizeof(a));
+            else launch(TFK_BT_RHS, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 2, 64, &a, sizeof(a));
             launch(l == 0 ? TFK_L1_ASM_RHS : TFK_BT_ASM_RHS, gx, 1, 64, &a, sizeof(a));
         }
         if (tail_from < levels.size()) launch_tail(false, rhs1, x1);
         else { TfTopArgs t = top_args(); launch(TFK_TOP_SOLVE, cdiv(nsys, 64), 1, 64, &t, sizeof(t)); }
         for (size_t l = tail_from; l-- > 0;) {
             TfLevelArgs a = level_args(l, rhs1, x1);
-            launch(l == 0 ? TFK_L1_BACKSUB : TFK_BT_BACKSUB, cdiv(a.L.Ptot, 64), 1, 64, &a, sizeof(a));
+            if (l == 0) launch(TFK_L1_BACKSUB, cdiv(a.L.Ptot, 64), 1, 64, &a, sizeof(a));
+            else launch(TFK_BT_BACKSUB, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
         }
     }
     void refine_sweep(const double* rhs1, double* x1) {
