@@ -78,6 +78,26 @@ def cpu_baseline(cfg, N, scheme_name):
                        "single thread, %.1f s" % (scheme_name, N, np.__version__, el))
 
 
+def scheme_api_rate(model, cfg, N, scheme_name, dt, steps=20):
+    """The same workload driven through the reference-style Python protocol
+    ``t, fields = scheme(t, fields, dt, pars)`` with device-resident containers
+    (informational; the timed region above uses the ensemble C-ABI loop)."""
+    from oracle import corpus
+    from triflow_amd import schemes
+    name, fd, pars, _, _ = corpus.config_inputs(cfg, N)
+    scheme = {"ROS2": schemes.ROS2, "Theta": schemes.Theta, "BDF2": schemes.BDF2,
+              "RODASPR": lambda m: schemes.RODASPR(m, time_stepping=False)}[scheme_name](model)
+    fields, t = model.fields_template(**fd), 0.0
+    for _ in range(3):
+        t, fields = scheme(t, fields, dt, pars)
+    fields._device_backing().stepper.solver.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        t, fields = scheme(t, fields, dt, pars)
+    fields._device_backing().stepper.solver.sync()
+    return steps / (time.perf_counter() - t0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,6 +213,8 @@ def main():
                          "avg_launch_ms": (sweep_ms / sweep_n) if sweep_n else None},
             "kernels_ms_per_step": {k: round(v[0] / nprof, 5) for k, v in report.items()},
         }
+        if world == 1 and args.members_per_gpu == 1:
+            out["scheme_api_steps_per_s"] = scheme_api_rate(model, args.config, N, scheme, dt)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, N, scheme)
         print(json.dumps(out))

@@ -115,8 +115,9 @@ int tf_step_row(tf_solver*, int32_t src, int32_t dst, double dt, int32_t s,
                 const double* b_pred, int32_t hook_after, double* err_out);
 int tf_step_bdf2(tf_solver*, int32_t src, int32_t dst, double dt);
 int tf_bdf2_reset(tf_solver*);
-/* max |state[a] - state[b]| over all variables and systems (one scalar); only
- * ord = 0 (the max norm) is implemented on the device */
+/* ||state[a] - state[b]||_ord of every dependent variable, out[nsys][nvar]; ord = 2
+ * or 0 (max norm): the error estimate of the step-doubling wrapper
+ * (schemes.py:41-44) without bringing the fields to the host */
 int tf_diff_norm(tf_solver*, int32_t slot_a, int32_t slot_b, int32_t ord, double* out);
 
 /* componentwise backward error max|b-Ax|/(|x|+|cJ||x|+|b|) measured on the first

@@ -70,6 +70,9 @@ void launch(Module*, int kernel, unsigned gx, unsigned gy, unsigned block,
         for (unsigned y = 0; y < gy; ++y) for (int64_t t = 0; t < nthreads; ++t) {
             double v = tfk_berr_body(a, (int)t, (int)y); m = (v > m || v != v) ? v : m; }
         *a.red = m; } break;
+    case TFK_DIFFNORM: { const auto& a = *(const TfNormArgs*)args;
+        for (unsigned y = 0; y < gy; ++y) for (unsigned b = 0; b < gx; ++b)
+            a.partial[(int64_t)y * a.nblocks + b] = tfk_diffnorm_partial(a, (int)y, (int)b, 0, 1); } break;
     case TFK_PERM: { const auto& a = *(const TfPermArgs*)args;
         for (int64_t t = 0; t < nthreads; ++t) tfk_perm_elem(a, t); } break;
     case TFK_DIRICHLET: { const auto& a = *(const TfDirichletArgs*)args;

@@ -282,3 +282,33 @@ def check_heat_steady_state(backend, scheme_cls, dirichlet):
             pass
         assert t == 100
         assert np.isclose(np.asarray(f["U"]).mean(), 0)
+
+
+def check_step_doubling_device_norm(backend):
+    """The step-doubling wrapper with the error norm reduced on the device
+    (containers untouched on the host) against the same run with host norms."""
+    m = device_model("M2_diff", backend)
+    fd = corpus.synthetic_fields("M2_diff", 80, seed=4)
+    pars = corpus.synthetic_pars("M2_diff", 80, True)
+    out = []
+    for force_host in (False, True):
+        scheme = schemes.time_stepping(schemes.Theta(m), tol=1e-2)
+        f, t = m.fields_template(**fd), 0.0
+        for _ in range(3):
+            t, f = scheme(t, f, 0.05, pars)
+            if force_host:
+                f["U"]                     # materialise: next call uploads, norms on host
+        out.append(f.uflat.copy())
+    assert np.abs(out[0] - out[1]).max() <= 1e-12 * np.abs(out[1]).max()
+    # the device-backed run really kept the norm on the GPU
+    a, b = m.fields_template(**fd), m.fields_template(**fd)
+    _, fa = schemes.Theta(m)(0.0, a, 0.01, pars)
+    _, fb = schemes.Theta(m)(0.0, fa, 0.01, pars)
+    n_dev = schemes._difference_norms(fa, fb, 2)
+    assert fa._device_backing() is not None and fb._device_backing() is not None
+    n_host = [np.linalg.norm(np.asarray(fa["U"]) - np.asarray(fb["U"]), 2)]
+    assert np.allclose(n_dev, n_host, rtol=1e-13)
+    n_dev_inf = None
+    _, fc = schemes.Theta(m)(0.0, fb, 0.01, pars)
+    n_dev_inf = schemes._difference_norms(fb, fc, np.inf)
+    assert np.allclose(n_dev_inf, [np.abs(np.asarray(fb["U"]) - np.asarray(fc["U"])).max()], rtol=0)

@@ -68,3 +68,7 @@ def test_errors(backend):
 
 def test_heat_steady_state(backend):
     pc.check_heat_steady_state(backend, schemes.RODASPR, dirichlet=False)
+
+
+def test_step_doubling_device_norm(backend):
+    pc.check_step_doubling_device_norm(backend)

@@ -166,3 +166,7 @@ def test_full_size_step_properties(cfg):
     assert np.isfinite(after).all()
     assert abs(after.mean() - before.mean()) <= 1e-11 * max(1.0, abs(before).max())
     assert not np.array_equal(before, after)
+
+
+def test_step_doubling_device_norm():
+    pc.check_step_doubling_device_norm(HIP)

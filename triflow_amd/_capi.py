@@ -291,10 +291,12 @@ class DeviceSolver:
     def bdf2_reset(self):
         self.lib.call("tf_bdf2_reset", self.handle)
 
-    def diff_maxnorm(self, slot_a, slot_b):
-        out = C.c_double(0.0)
-        self.lib.call("tf_diff_norm", self.handle, slot_a, slot_b, 0, C.byref(out))
-        return out.value
+    def diff_norms(self, slot_a, slot_b, ord=2):
+        """||state[a] - state[b]|| per system and dependent variable, [nsys][nvar]."""
+        out = np.empty((self.nsys, self.nvar))
+        self.lib.call("tf_diff_norm", self.handle, slot_a, slot_b,
+                      0 if ord in (0, np.inf, "inf") else int(ord), _dptr(out))
+        return out
 
     def backward_error(self):
         """(componentwise backward error of the checked solve, refinement active?)"""

@@ -65,6 +65,24 @@ __global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_berr(TfBerrArgs a) {
     if ((threadIdx.x & 63) == 0 && bits != 0) atomicMax((unsigned long long*)a.red, bits);
 }
 
+// grid (nblocks, nvar*nsys): deterministic tree inside the block, one partial per block
+__global__ void __launch_bounds__(256) tfk_diffnorm(TfNormArgs a) {
+    double acc = tfk_diffnorm_partial(a, blockIdx.y, blockIdx.x, threadIdx.x, blockDim.x);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(acc, off, 64);
+        acc = a.ord == 2 ? acc + o : (o > acc ? o : acc);
+    }
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+            acc = a.ord == 2 ? acc + part[w] : (part[w] > acc ? part[w] : acc);
+        a.partial[(int64_t)blockIdx.y * a.nblocks + blockIdx.x] = acc;
+    }
+}
+
 __global__ void __launch_bounds__(256) tfk_perm(TfPermArgs a) {
     tfk_perm_elem(a, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }

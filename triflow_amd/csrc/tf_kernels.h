@@ -310,6 +310,25 @@ TF_DEVICE void tfk_perm_elem(const TfPermArgs& a, int64_t t) {
     }
 }
 
+// (a - b) of variable/system `vs` restricted to the slice of work item (blk, tid):
+// this thread's partial sum of squares (ord 2) or maximum (ord 0)
+TF_DEVICE double tfk_diffnorm_partial(const TfNormArgs& a, int vs, int blk, int tid, int nthreads) {
+    const TfLayout& L = a.L;
+    const int v = vs / L.nsys, e = vs - v * L.nsys;
+    const int64_t total = (int64_t)L.M * L.P;
+    const int64_t per = (total + a.nblocks - 1) / a.nblocks;
+    const int64_t lo = (int64_t)blk * per, hi = lo + per < total ? lo + per : total;
+    double acc = 0.0;
+    for (int64_t q = lo + tid; q < hi; q += nthreads) {
+        const int64_t i = q / L.P, p = q - i * L.P;
+        const int64_t s = (int64_t)v * L.plane + i * L.Ptot + (int64_t)e * L.P + p;
+        const double d = a.a[s] - a.b[s];
+        if (a.ord == 2) acc = tf_fma(d, d, acc);
+        else acc = tf_abs(d) > acc ? tf_abs(d) : acc;
+    }
+    return acc;
+}
+
 // declarative Dirichlet hook: U[var][node] = value in every system
 TF_DEVICE void tfk_dirichlet_elem(const TfDirichletArgs& a, int t) {
     const TfLayout& L = a.L;

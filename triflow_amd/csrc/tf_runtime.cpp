@@ -95,7 +95,7 @@ struct tf_solver {
     std::vector<std::unique_ptr<DevBuf>> state;     // [nstate] x nvar planes
     DevBuf helpers, parvec, parsca, dx, xcoord;
     DevBuf F, Jv, Wstage, Wsum, Wjv, Wrhs, Wres, Wdel, Uprev, K[TF_MAX_TERMS];
-    DevBuf staging;
+    DevBuf staging, normbuf;
     DevBuf red;            // reduction scalars
     int* status = nullptr;
     std::vector<std::unique_ptr<Level>> levels;     // chunk levels; the last one has P == 1
@@ -777,15 +777,24 @@ int tf_bdf2_reset(tf_solver* s) {
 int tf_diff_norm(tf_solver* s, int32_t slot_a, int32_t slot_b, int32_t ord, double* out) {
     TF_API_BEGIN
     require(s && out, "null argument");
-    require(ord == 0, "tf_diff_norm: only the max norm (ord = 0) is implemented on the device");
-    // max |a - b| over everything (all variables, all systems): one scalar
-    const double* xs[2] = {s->st(slot_a), s->st(slot_b)};
-    const double cs[2] = {1.0, -1.0};
-    tfb::memset0(s->red.p, sizeof(double), s->stream);
-    s->vec(TF_VEC_MAXABS, nullptr, nullptr, 2, xs, cs);
-    uint64_t bits = 0;
-    tfb::d2h(&bits, s->red.p, sizeof(bits), s->stream);
-    std::memcpy(out, &bits, sizeof(double));
+    require(ord == 0 || ord == 2, "tf_diff_norm: ord must be 2 or 0 (max norm)");
+    const int nb = 64, nvs = s->spec.nvar * s->nsys;
+    if (s->normbuf.n < (size_t)nb * nvs) s->normbuf.alloc((size_t)nb * nvs, s->bytes);
+    TfNormArgs a;
+    a.L = s->L1; a.a = s->st(slot_a); a.b = s->st(slot_b); a.partial = s->normbuf.p;
+    a.nblocks = nb; a.ord = ord;
+    s->launch(TFK_DIFFNORM, nb, nvs, 256, &a, sizeof(a));
+    std::vector<double> part((size_t)nb * nvs);
+    tfb::d2h(part.data(), s->normbuf.p, part.size() * sizeof(double), s->stream);
+    for (int vs = 0; vs < nvs; ++vs) {                 // fixed order: deterministic
+        double acc = 0.0;
+        for (int b = 0; b < nb; ++b) {
+            const double v = part[(size_t)vs * nb + b];
+            acc = ord == 2 ? acc + v : (v > acc ? v : acc);
+        }
+        const int v = vs / s->nsys, e = vs % s->nsys;
+        out[(size_t)e * s->spec.nvar + v] = ord == 2 ? std::sqrt(acc) : acc;
+    }
     TF_API_END
 }
 
