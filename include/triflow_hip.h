@@ -93,6 +93,11 @@ int tf_set_x(tf_solver*, const double* x /*[nsys][N]*/);
 int tf_set_dirichlet(tf_solver*, int32_t n, const int32_t* var, const int64_t* node,
                      const double* value);
 
+/* time-dependent boundary values: `before` is applied where the reference calls
+ * hook(t, ...) at the start of a step, `after` where it calls hook(t + dt, ...)
+ * (either may be NULL = unchanged); same entries as the last tf_set_dirichlet */
+int tf_set_dirichlet_values(tf_solver*, const double* before, const double* after);
+
 /* ---- seam #1: F / J evaluation on the resident state ----------------------- */
 int tf_eval(tf_solver*, int32_t slot, int32_t with_j);
 /* `reps` back-to-back sweeps between two HIP events on the solver's stream */

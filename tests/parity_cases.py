@@ -312,3 +312,33 @@ def check_step_doubling_device_norm(backend):
     _, fc = schemes.Theta(m)(0.0, fb, 0.01, pars)
     n_dev_inf = schemes._difference_norms(fb, fc, np.inf)
     assert np.allclose(n_dev_inf, [np.abs(np.asarray(fb["U"]) - np.asarray(fc["U"])).max()], rtol=0)
+
+
+def check_time_dependent_hook(backend):
+    """Time-dependent Dirichlet data and a time-dependent parameter, served on
+    the device by a declarative hook, against the oracle running the same hook as
+    a plain Python callable on the host."""
+    values = dict(U={0: lambda t: 1.0 + 0.5 * np.sin(3 * t), -1: 0.25})
+    kfun = lambda t, pars: dict(k=1e-3 * (1.0 + t))
+    dev_hook = DirichletHook(parameters=kfun, **values)
+
+    def host_hook(t, fields, pars):
+        fields["U"][0] = 1.0 + 0.5 * np.sin(3 * t)
+        fields["U"][-1] = 0.25
+        return fields, dict(pars, **kfun(t, pars))
+
+    for make_dev, make_ora in ((lambda m: schemes.Theta(m), lambda m: ora.Theta(m)),
+                               (lambda m: schemes.ROS2(m), lambda m: ora.ROS2(m)),
+                               (lambda m: schemes.ROS3PRL(m, time_stepping=False),
+                                lambda m: ora.ROS3PRL(m, time_stepping=False))):
+        m, mo = device_model("M1_advdiff", backend), oracle_model("M1_advdiff")
+        _, fd, pars, dt, _ = corpus.config_inputs(1, 60)
+        s_dev, s_ora = make_dev(m), make_ora(mo)
+        f_dev, f_ora = m.fields_template(**fd), mo.fields_template(**fd)
+        t = 0.0
+        for k in range(4):
+            _, f_dev = s_dev(t, f_dev, dt, pars, hook=dev_hook)
+            assert f_dev._device_backing() is not None        # never left the GPU
+            t, f_ora = s_ora(t, f_ora, dt, pars, hook=host_hook)
+        err = np.abs(f_dev.uflat - f_ora.uflat).max() / np.abs(f_ora.uflat).max()
+        assert err <= 1e-11, err

@@ -72,3 +72,7 @@ def test_heat_steady_state(backend):
 
 def test_step_doubling_device_norm(backend):
     pc.check_step_doubling_device_norm(backend)
+
+
+def test_time_dependent_hook(backend):
+    pc.check_time_dependent_hook(backend)

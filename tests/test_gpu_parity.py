@@ -170,3 +170,7 @@ def test_full_size_step_properties(cfg):
 
 def test_step_doubling_device_norm():
     pc.check_step_doubling_device_norm(HIP)
+
+
+def test_time_dependent_hook():
+    pc.check_time_dependent_hook(HIP)

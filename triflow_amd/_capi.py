@@ -48,6 +48,7 @@ SIGNATURES = {
     "tf_set_dx": (C.c_int, [C.c_void_p, c_double_p]),
     "tf_set_x": (C.c_int, [C.c_void_p, c_double_p]),
     "tf_set_dirichlet": (C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int64_p, c_double_p]),
+    "tf_set_dirichlet_values": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "tf_eval": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "tf_eval_repeat": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_double_p]),
     "tf_get_F": (C.c_int, [C.c_void_p, c_double_p]),
@@ -232,6 +233,12 @@ class DeviceSolver:
         val = np.array([e[2] for e in entries], dtype=np.float64)
         self.lib.call("tf_set_dirichlet", self.handle, n,
                       var.ctypes.data_as(c_int32_p), node.ctypes.data_as(c_int64_p), _dptr(val))
+
+    def set_dirichlet_values(self, before=None, after=None):
+        b = _f64(before) if before is not None else None
+        a = _f64(after) if after is not None else None
+        self.lib.call("tf_set_dirichlet_values", self.handle,
+                      _dptr(b) if b is not None else None, _dptr(a) if a is not None else None)
 
     # ----------------------------------------------------------------- seam #1
     def eval(self, slot=0, with_j=False):

@@ -109,7 +109,7 @@ struct tf_solver {
     // declarative Dirichlet hook
     int ndir = 0;
     int *dir_var = nullptr, *dir_node = nullptr;
-    DevBuf dir_val;
+    DevBuf dir_val, dir_val_post;   // values applied before the step (hook at t) / after (t+dt)
 
     // BDF-2 history
     bool bdf_have_prev = false;
@@ -212,10 +212,11 @@ struct tf_solver {
         tfb::d2h(host, staging.p, cnt * sizeof(double), stream);
     }
 
-    void apply_dirichlet(double* fields) {
+    void apply_dirichlet(double* fields, bool post = false) {
         if (ndir == 0) return;
         TfDirichletArgs a;
-        a.L = L1; a.fields = fields; a.n = ndir; a.var = dir_var; a.node = dir_node; a.value = dir_val.p;
+        a.L = L1; a.fields = fields; a.n = ndir; a.var = dir_var; a.node = dir_node;
+        a.value = post ? dir_val_post.p : dir_val.p;
         launch(TFK_DIRICHLET, cdiv((int64_t)ndir * nsys, 64), 1, 64, &a, sizeof(a));
     }
 
@@ -584,15 +585,27 @@ int tf_set_dirichlet(tf_solver* s, int32_t n, const int32_t* var, const int64_t*
         s->dir_node = (int*)tfb::dev_alloc(sizeof(int) * n);
         int64_t dummy = 0;
         s->dir_val.alloc(n, dummy);
+        s->dir_val_post.alloc(n, dummy);
         tfb::h2d(s->dir_var, var, sizeof(int) * n, s->stream);
         tfb::h2d(s->dir_node, nodes.data(), sizeof(int) * n, s->stream);
         tfb::h2d(s->dir_val.p, value, sizeof(double) * n, s->stream);
+        tfb::h2d(s->dir_val_post.p, value, sizeof(double) * n, s->stream);
         s->ndir = n;
     }
     TF_API_END
 }
 
 // --------------------------------------------------------------- seam #1
+int tf_set_dirichlet_values(tf_solver* s, const double* before, const double* after) {
+    TF_API_BEGIN
+    require(s, "null solver");
+    if (s->ndir > 0) {
+        if (before) tfb::h2d(s->dir_val.p, before, sizeof(double) * s->ndir, s->stream);
+        if (after) tfb::h2d(s->dir_val_post.p, after, sizeof(double) * s->ndir, s->stream);
+    }
+    TF_API_END
+}
+
 int tf_eval(tf_solver* s, int32_t slot, int32_t with_j) {
     TF_API_BEGIN
     require(s, "null solver");
@@ -676,7 +689,7 @@ int tf_step_theta(tf_solver* s, int32_t src, int32_t dst, double dt, double thet
     s->solve(s->Wrhs.p, s->Wstage.p);
     const double* cp[1] = {s->Wstage.p};
     s->vec(TF_VEC_COPY, U, nullptr, 1, cp, nullptr);
-    s->apply_dirichlet(U);
+    s->apply_dirichlet(U, true);
     TF_API_END
 }
 
@@ -720,7 +733,7 @@ int tf_step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns,
         for (int j = 0; j < ns; ++j) cs[j] = b_pred[j];
         s->vec(TF_VEC_MAXABS, nullptr, U, ns, ks, cs);             // ||U - (U + sum b_pred k)||_inf
     }
-    if (hook_after) s->apply_dirichlet(U);
+    if (hook_after) s->apply_dirichlet(U, true);
     if (err_out) {
         *err_out = 0.0;
         if (b_pred) {
@@ -764,7 +777,7 @@ int tf_step_bdf2(tf_solver* s, int32_t src, int32_t dst, double dt) {
     s->solve(s->Wrhs.p, s->Wdel.p);
     const double* ys[2] = {U, s->Wdel.p};
     s->vec(TF_VEC_ADD, U, nullptr, 2, ys, nullptr);
-    s->apply_dirichlet(U);
+    s->apply_dirichlet(U, true);
     TF_API_END
 }
 int tf_bdf2_reset(tf_solver* s) {

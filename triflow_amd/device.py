@@ -27,7 +27,7 @@ def null_hook(t, fields, pars):
 
 
 class DirichletHook:
-    """Declarative boundary hook, e.g. ``DirichletHook(U={0: 1.0, -1: 0.0})``.
+    """Declarative hook, e.g. ``DirichletHook(U={0: 1.0, -1: 0.0})``.
 
     Equivalent to the reference idiom (``README.md:126-129``)::
 
@@ -36,24 +36,47 @@ class DirichletHook:
             return fields, pars
 
     and usable as such on host containers, but recognised by the device schemes
-    and applied in place on the GPU.
+    and applied in place on the GPU, at the places and with the times the
+    reference calls ``hook`` (``schemes.py:139,145,549,558``).  A value may be a
+    callable of ``t`` (time-dependent boundary data); ``parameters`` may be a
+    callable ``(t, pars) -> dict`` of parameter updates (time-dependent
+    coefficients) -- neither needs the fields on the host.
     """
 
-    def __init__(self, **values):
+    def __init__(self, parameters=None, **values):
         self.values = {var: dict(nodes) for var, nodes in values.items()}
+        self.parameters = parameters
+
+    def update_pars(self, t, pars):
+        if self.parameters is None:
+            return pars
+        new = dict(pars)
+        new.update(self.parameters(t, pars))
+        return new
 
     def __call__(self, t, fields, pars):
         for var, nodes in self.values.items():
             for node, value in nodes.items():
-                fields[var][node] = value
-        return fields, pars
+                fields[var][node] = value(t) if callable(value) else value
+        return fields, self.update_pars(t, pars)
 
-    def entries(self, dependent_variables):
-        out = []
-        for var, nodes in self.values.items():
-            idx = list(dependent_variables).index(var)
-            out.extend((idx, int(node), float(value)) for node, value in nodes.items())
-        return out
+    def layout(self, dependent_variables):
+        """Static part: (variable index, node) of every entry."""
+        dep = list(dependent_variables)
+        return tuple((dep.index(var), int(node))
+                     for var, nodes in self.values.items() for node in nodes)
+
+    def values_at(self, t):
+        return [float(v(t)) if callable(v) else float(v)
+                for nodes in self.values.values() for v in nodes.values()]
+
+    @property
+    def time_dependent(self):
+        return any(callable(v) for nodes in self.values.values() for v in nodes.values())
+
+    def entries(self, dependent_variables, t=0.0):
+        return [(i, n, v) for (i, n), v in zip(self.layout(dependent_variables),
+                                               self.values_at(t))]
 
 
 class DeviceBacking:
@@ -165,12 +188,25 @@ class Stepper:
         cm.bind_inputs(self.solver, x, values, helpers)
         self._bound_pars, self._bound_x = pkey, xkey
 
-    def set_hook(self, hook):
-        entries = tuple(hook.entries(self.compiled.model._dep_vars)) \
-            if isinstance(hook, DirichletHook) else ()
-        if entries != self._dirichlet:
-            self.solver.set_dirichlet(entries)
-            self._dirichlet = entries
+    def set_hook(self, hook, t=0.0, t_after=None):
+        """Boundary values the step kernels apply before (``t``) and after
+        (``t_after``) the step."""
+        if not isinstance(hook, DirichletHook):
+            if self._dirichlet:
+                self.solver.set_dirichlet(())
+                self._dirichlet = ()
+            return
+        layout = hook.layout(self.compiled.model._dep_vars)
+        before = hook.values_at(t)
+        after = hook.values_at(t if t_after is None else t_after)
+        key = (layout, tuple(before), tuple(after))
+        if key == self._dirichlet:
+            return
+        if self._dirichlet is None or not self._dirichlet or self._dirichlet[0] != layout:
+            self.solver.set_dirichlet([(i, n, v) for (i, n), v in zip(layout, before)])
+        if layout:
+            self.solver.set_dirichlet_values(before, after)
+        self._dirichlet = key
 
 
 def stepper_for(model, fields, pars, **opts):

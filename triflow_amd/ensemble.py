@@ -72,7 +72,7 @@ class Ensemble:
                                     for k in model._help_funcs]))
         s.set_state(0, np.array([np.broadcast_to(fields[k], (self.nsys, self.N)) for k in dep]))
         if hook is not None:
-            s.set_dirichlet(hook.entries(dep))
+            s.set_dirichlet(hook.entries(dep, 0.0))
         self.scheme, self.theta = scheme, theta
         self.tab = TABLEAUX.get(scheme)
         self.cur, self.t = 0, 0.0

@@ -42,15 +42,17 @@ def _is_device_hook(hook):
         getattr(hook, "__name__", "") == "null_hook"
 
 
-def _device_step(model, t, fields, pars, hook, launch):
+def _device_step(model, t, fields, pars, hook, launch, dt=None):
     """Common prologue of every scheme: resident source slot (uploading when the
     caller handed over host data), hook at ``t``, one device step into a free
     slot.  ``launch(solver, src, dst)`` issues the kernels; returns
     ``(new_fields, pars, launch result)``."""
     if _is_device_hook(hook):
+        if isinstance(hook, DirichletHook):
+            pars = hook.update_pars(t, pars)          # hook(t, ...) may return new parameters
         stepper = stepper_for(model, fields, pars)
         stepper.bind(fields, pars)
-        stepper.set_hook(hook)
+        stepper.set_hook(hook, t, None if dt is None else t + dt)
         src = stepper.acquire(fields)
         template = fields
     else:
@@ -124,7 +126,7 @@ class Theta:
             return self._host_solver_step(t, fields, dt, pars, hook)
         new, pars, _ = _device_step(
             self._model, t, fields, pars, hook,
-            lambda solver, src, dst: solver.step_theta(src, dst, dt, self._theta))
+            lambda solver, src, dst: solver.step_theta(src, dst, dt, self._theta), dt=dt)
         if not _is_device_hook(hook):
             new, _ = hook(t + dt, new, pars)
         return t + dt, new
@@ -184,7 +186,7 @@ class ROW_general:
             return solver.step_row(src, dst, dt, self._alpha, self._gamma, self._b,
                                    self._b_pred, hook_after=hook_after and device_hook,
                                    want_err=want_err and self._b_pred is not None)
-        new, pars, err = _device_step(self._model, t, fields, pars, hook, launch)
+        new, pars, err = _device_step(self._model, t, fields, pars, hook, launch, dt=dt)
         if hook_after and not device_hook:
             new, pars = hook(t + dt, new, pars)
         return t + dt, new, err
@@ -281,7 +283,7 @@ class BDF2:
                 solver.bdf2_reset()
                 self._stepper = solver
             solver.step_bdf2(src, dst, dt)
-        new, pars, _ = _device_step(self._model, t, fields, pars, hook, launch)
+        new, pars, _ = _device_step(self._model, t, fields, pars, hook, launch, dt=dt)
         if not _is_device_hook(hook):
             new, _ = hook(t + dt, new, pars)
         return t + dt, new
