@@ -174,3 +174,32 @@ def test_step_doubling_device_norm():
 
 def test_time_dependent_hook():
     pc.check_time_dependent_hook(HIP)
+
+
+# ---- BASELINE configurations against the oracle at sizes it still finishes in seconds ----
+@pytest.mark.parametrize("cfg,N,nsteps,tol", [(2, 10 ** 6, 2, 2e-8), (3, 2 * 10 ** 5, 2, 5e-7),
+                                              (5, 4 * 10 ** 5, 3, 1e-9)])
+def test_config_steps_vs_oracle(cfg, N, nsteps, tol):
+    """Configs 2 (full size), 3 and 5 (1/5 and 1/10 size, same dx scaling rules as
+    corpus.config_inputs): the configured scheme on the device against the oracle
+    (reference algorithm + SuperLU).  Tolerances: cond(A)*eps of the reference's own
+    solve: config 2 at N = 1e6 has cond(I - dt J) = 4e7 (measured 1.4e-9),
+    the film model reaches 2e10 at the full size."""
+    from oracle import numpy_path as ora
+    name, fd, pars, dt, sch = corpus.config_inputs(cfg, N)
+    m, mo = pc.device_model(name, HIP), pc.oracle_model(name)
+    dev = {"Theta": schemes.Theta, "ROS2": schemes.ROS2, "BDF2": schemes.BDF2}[sch](m)
+    ref = {"Theta": ora.Theta, "ROS2": ora.ROS2, "BDF2": ora.BDF2}[sch](mo)
+    kw_d = dict(hook=pc.DEVICE_HOOKS["cfg5"]) if cfg == 5 else {}
+    kw_o = dict(hook=corpus.dirichlet_hook_cfg5) if cfg == 5 else {}
+    f_d, f_o = m.fields_template(**fd), mo.fields_template(**fd)
+    t = 0.0
+    for k in range(nsteps):
+        _, f_d = dev(t, f_d, dt, pars, **kw_d)
+        t, f_o = ref(t, f_o, dt, pars, **kw_o)
+    omega, refined = f_d._device_backing().stepper.solver.backward_error()
+    u_d, u_o = f_d.uflat, f_o.uflat
+    err = np.abs(u_d - u_o).max() / np.abs(u_o).max()
+    print("config %d N=%d: rel err vs oracle %.2e, backward error %.1e" % (cfg, N, err, omega))
+    assert err <= tol, (cfg, err)
+    assert omega < 1e-10 and not refined
