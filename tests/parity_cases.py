@@ -342,3 +342,59 @@ def check_time_dependent_hook(backend):
             t, f_ora = s_ora(t, f_ora, dt, pars, hook=host_hook)
         err = np.abs(f_dev.uflat - f_ora.uflat).max() / np.abs(f_ora.uflat).max()
         assert err <= 1e-11, err
+
+
+#: the models of the reference's example notebooks (examples/notebooks/*.ipynb) with
+#: their grids, parameters and time steps
+NOTEBOOK_CASES = {
+    "burgers_kdv": (("-U * dxU + a * dxxU + b * dxxxU", "U", ["a", "b"]),
+                    lambda: np.linspace(-2, 6, 5000, endpoint=False),
+                    dict(a=2e-4, b=1e-4, periodic=False), 0.05),
+    "kuramoto": (("-dxxzeta - dxxxxzeta + (dxzeta)**2", "zeta"),
+                 lambda: np.linspace(0, 200, 2010), dict(periodic=True), 0.2),
+    "droplet": (("dx((h**3 + h**2) * dx(-sigma * dxxh + alpha * (1 / h**3 - e / h**4)))",
+                 "h", ["sigma", "alpha", "e"]),
+                lambda: np.linspace(0, 10, 200),
+                dict(periodic=False, alpha=.05, sigma=10, e=1e-1), 0.01),
+    "so_wavy": ((["k * dxxU - c * U * dxV", "k * dxxV - c * V * dxU"], ["U", "V"], ["k", "c"]),
+                lambda: np.linspace(0, 100, 500, endpoint=False),
+                dict(k=1, c=10, periodic=True), 0.1),
+}
+
+
+def check_notebook_model(name, backend):
+    """Three steps of Theta and of fixed-step RODASPR on a model of the reference's
+    example notebooks, device path vs oracle."""
+    margs, grid, pars, dt = NOTEBOOK_CASES[name]
+    x = grid()
+    compiler = hip_compiler if backend is None else partial(hip_compiler, backend=backend)
+    m = Model(*margs, compiler=compiler)
+    mo = Model(*margs, compiler=ora.numpy_compiler)
+    if name == "burgers_kdv":
+        fd = dict(x=x, U=np.exp(-x ** 2 * 4))
+    elif name == "kuramoto":
+        fd = dict(x=x, zeta=np.cos(x * 2 * np.pi / x.max() * 10) * 2 + 5)
+    elif name == "droplet":
+        fd = dict(x=x, h=np.exp(-0.5 * ((x - 5) / 1.0) ** 2) + 1e-1)
+    else:
+        fd = dict(x=x, U=np.cos(x * 2 * np.pi / 100 * 3), V=np.sin(x * 2 * np.pi / 100 * 2))
+    F = m.F(m.fields_template(**fd), pars)
+    Fo = mo.F(mo.fields_template(**fd), pars)
+    if name == "droplet":
+        # h**3, h**4, h**5 of a *field*: NumPy calls its libm / SVML pow (not correctly
+        # rounded, and not the same on every CPU); the kernel rounds the exact power
+        # once.  1-ulp differences of those terms are amplified by cancellation.
+        assert np.abs(F - Fo).max() <= 1e-12 * np.abs(Fo).max()
+    else:
+        assert np.array_equal(F, Fo)
+    for mk_d, mk_o in ((lambda mm: schemes.Theta(mm), lambda mm: ora.Theta(mm)),
+                       (lambda mm: schemes.RODASPR(mm, time_stepping=False),
+                        lambda mm: ora.RODASPR(mm, time_stepping=False))):
+        sd, so = mk_d(m), mk_o(mo)
+        f_d, f_o = m.fields_template(**fd), mo.fields_template(**fd)
+        t = 0.0
+        for _ in range(3):
+            _, f_d = sd(t, f_d, dt, pars)
+            t, f_o = so(t, f_o, dt, pars)
+        err = np.abs(f_d.uflat - f_o.uflat).max() / np.abs(f_o.uflat).max()
+        assert err <= 1e-9, (name, err)

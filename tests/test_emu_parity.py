@@ -76,3 +76,8 @@ def test_step_doubling_device_norm(backend):
 
 def test_time_dependent_hook(backend):
     pc.check_time_dependent_hook(backend)
+
+
+@pytest.mark.parametrize("name", sorted(pc.NOTEBOOK_CASES))
+def test_notebook_models(name, backend):
+    pc.check_notebook_model(name, backend)

@@ -203,3 +203,8 @@ def test_config_steps_vs_oracle(cfg, N, nsteps, tol):
     print("config %d N=%d: rel err vs oracle %.2e, backward error %.1e" % (cfg, N, err, omega))
     assert err <= tol, (cfg, err)
     assert omega < 1e-10 and not refined
+
+
+@pytest.mark.parametrize("name", sorted(pc.NOTEBOOK_CASES))
+def test_notebook_models(name):
+    pc.check_notebook_model(name, HIP)

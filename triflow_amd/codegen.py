@@ -55,6 +55,15 @@ class _CEmitter(ast.NodeVisitor):
         self.denominators = {}      # C expression -> index
         self.den_count = {}         # C expression -> number of quotients using it
         self.shared = {}            # den_count of a previous pass over the same expressions
+        self.host_consts = {}       # python source of a uniform pow()/libm call -> index
+
+    def host_const(self, node):
+        """A node-independent power or libm call (``dx**3``, ``exp(k)``): evaluated on
+        the host with NumPy -- i.e. by the very libm the reference's lambdified code
+        calls -- and handed to the kernel as an extra scalar, so its bits match."""
+        src = ast.unparse(node)
+        k = self.host_consts.setdefault(src, len(self.host_consts))
+        return "tf_hc[%d]" % k
 
     def is_uniform(self, node):
         if isinstance(node, ast.Constant):
@@ -115,6 +124,8 @@ class _CEmitter(ast.NodeVisitor):
         raise UnsupportedExpression(ast.dump(node))
 
     def _pow(self, node):
+        if self.is_uniform(node) and not isinstance(node.left, ast.Constant):
+            return self.host_const(node)
         base = self.visit(node.left)
         expo = node.right
         neg = False
@@ -162,6 +173,9 @@ class _CEmitter(ast.NodeVisitor):
             fn = "tf_max" if name == "maximum" else "tf_min"
             return "%s(%s, %s)" % (fn, self.visit(node.args[0]), self.visit(node.args[1]))
         if name in _FUNCS_1 and len(node.args) == 1:
+            if self.is_uniform(node.args[0]) and not isinstance(node.args[0], ast.Constant) \
+                    and name not in ("abs", "absolute", "fabs", "sign", "floor", "ceil", "sqrt"):
+                return self.host_const(node)
             return "%s(%s)" % (_FUNCS_1[name], self.visit(node.args[0]))
         raise UnsupportedExpression("function %r is not supported by the HIP compiler" % name)
 
@@ -228,12 +242,15 @@ def lower_model(model, parvec_mask=0, seg=8, sweep_block=64):
     uniform = {"dx"} | {name for k, name in enumerate(pars) if not (parvec_mask >> k) & 1}
     f_nodes = _printed_expressions(model._symbolic_args, model.F_array.tolist())
     j_nodes = _printed_expressions(model._symbolic_args, model._J_sparse_array.tolist())
+    host_consts = {}
+
     def emit_all(nodes):
         first = _CEmitter(names, uniform)           # pass 1: count divisor reuse
         for n in nodes:
             first.visit(n)
         second = _CEmitter(names, uniform)
         second.shared = first.den_count
+        second.host_consts = host_consts            # one table for F and J
         return second, [second.visit(n) for n in nodes]
 
     emit_f, f_c = emit_all(f_nodes)
@@ -242,7 +259,8 @@ def lower_model(model, parvec_mask=0, seg=8, sweep_block=64):
 
     def body(outname, exprs, emitter):
         lines = ["    " + d for d in decls]
-        lines += ["    (void)dx; (void)xc; (void)par;"]
+        lines += ["    const double* tf_hc = par + %d;" % len(pars)]
+        lines += ["    (void)dx; (void)xc; (void)par; (void)tf_hc;"]
         # node-independent divisors and their reciprocals: loop invariant, hoisted
         for den, k in sorted(emitter.denominators.items(), key=lambda kv: kv[1]):
             lines += ["    const double tf_den%d = %s;" % (k, den),
@@ -254,7 +272,10 @@ def lower_model(model, parvec_mask=0, seg=8, sweep_block=64):
         vals = ", ".join(str(v) for v in values) if values else "0"
         return "static constexpr %s %s[%d] = {%s};" % (ctype, name, max(len(values), 1), vals)
 
-    par_is_vec = [1 if (parvec_mask >> k) & 1 else 0 for k in range(len(pars))]
+    hc_list = [src_ for src_, _ in sorted(host_consts.items(), key=lambda kv: kv[1])]
+    par_is_vec = [1 if (parvec_mask >> k) & 1 else 0 for k in range(len(pars))] + [0] * len(hc_list)
+    if len(pars) + len(hc_list) > 16:
+        raise UnsupportedExpression("too many parameters + host constants for the HIP skeleton")
     src = "\n".join([
         "// generated by triflow_amd.codegen -- do not edit",
         "// equations: " + " ; ".join(str(e) for e in model._diff_eqs),
@@ -262,7 +283,7 @@ def lower_model(model, parvec_mask=0, seg=8, sweep_block=64):
         "#define TF_NH %d" % nh,
         "#define TF_MP %d" % mp,
         "#define TF_NNZ %d" % nnz,
-        "#define TF_NPAR %d" % len(pars),
+        "#define TF_NPAR %d" % (len(pars) + len(host_consts)),
         "#define TF_SEG %d" % seg,
         "#define TF_SWEEP_BLOCK %d" % sweep_block,
         "#define TF_USES_X %d" % (1 if uses_x else 0),
@@ -277,11 +298,30 @@ def lower_model(model, parvec_mask=0, seg=8, sweep_block=64):
         body("J", j_c, emit_j),
         "}",
         ""])
-    spec = dict(nvar=nvar, nh=nh, npar=len(pars), mp=mp, nnz=nnz, seg=seg,
+    spec = dict(nvar=nvar, nh=nh, npar=len(pars) + len(hc_list), npar_model=len(pars),
+                host_consts=hc_list, mp=mp, nnz=nnz, seg=seg,
                 sweep_block=sweep_block, uses_x=int(uses_x), parvec_mask=int(parvec_mask),
                 b2=mp * nvar, pat_eq=pat_eq, pat_var=pat_var, pat_off=pat_off,
                 fields=fields, pars=pars)
     return src, spec
+
+
+_HOST_NS = {name: getattr(np, name) for name in
+            ("sqrt", "exp", "log", "sin", "cos", "tan", "tanh", "sinh", "cosh", "arctan", "arcsin",
+             "arccos", "log10", "log2", "cbrt", "expm1", "log1p", "maximum", "minimum", "pi")}
+_HOST_NS["E"] = np.e
+
+
+def eval_host_constants(spec, dx, par_values):
+    """Values of the model's uniform power / libm sub-expressions for one system,
+    computed exactly as the reference's lambdified NumPy code computes them."""
+    env = {name: np.float64(np.ravel(v)[0]) for name, v in zip(spec["pars"], par_values)}
+    env["dx"] = np.float64(dx)
+    out = []
+    for src_ in spec["host_consts"]:
+        with np.errstate(all="ignore"):
+            out.append(float(eval(src_, {"__builtins__": {}, **_HOST_NS}, env)))
+    return out
 
 
 def _tokens(text):

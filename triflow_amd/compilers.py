@@ -271,14 +271,19 @@ class CompiledModel:
         return mask
 
     def bind_inputs(self, solver, x, par_values, helper_arrays=None):
-        solver.set_dx(self.grid_spacing(x))
+        spec = solver.model.spec
+        dx = self.grid_spacing(x)
+        solver.set_dx(dx)
         solver.set_x(x)
-        mask = solver.model.spec["parvec_mask"]
+        mask = spec["parvec_mask"]
         for k, v in enumerate(par_values):
             if (mask >> k) & 1:
                 solver.set_param(k, np.asarray(v, dtype=float))
             else:
                 solver.set_param(k, float(np.ravel(v)[0]))
+        # node-independent pow()/libm sub-expressions, evaluated with NumPy on the host
+        for j, value in enumerate(codegen.eval_host_constants(spec, dx, par_values)):
+            solver.set_param(spec["npar_model"] + j, value)
         if self.nh and helper_arrays is not None:
             solver.set_helpers(np.asarray(helper_arrays, dtype=float))
 

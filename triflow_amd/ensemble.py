@@ -67,6 +67,15 @@ class Ensemble:
         s.set_x(x)
         for k, v in enumerate(values):
             s.set_param(k, v)
+        spec = s.model.spec
+        dxs = (x[:, -1] - x[:, 0]) / (self.N - 1)
+        if spec["host_consts"]:
+            from . import codegen
+            per_member = [codegen.eval_host_constants(
+                spec, dxs[e], [np.asarray(v)[e] if np.ndim(v) >= 1 and np.shape(v)[0] == self.nsys
+                               else v for v in values]) for e in range(self.nsys)]
+            for j in range(len(spec["host_consts"])):
+                s.set_param(spec["npar_model"] + j, np.array([pm[j] for pm in per_member]))
         if cm.nh:
             s.set_helpers(np.array([np.broadcast_to(fields[k], (self.nsys, self.N))
                                     for k in model._help_funcs]))
