@@ -44,8 +44,8 @@ def member_table(n_members, base):
 
 
 def build_problem(cfg, N, table):
-    from oracle import corpus
-    name, fd, pars, dt, scheme = corpus.config_inputs(cfg, N)
+    from triflow_amd import workloads
+    name, fd, pars, dt, scheme = workloads.config_inputs(cfg, N)
     nm = table.shape[0]
     fields = {k: np.repeat(v[None, :], nm, axis=0) for k, v in fd.items() if k != "x"}
     pars = dict(pars)
@@ -63,28 +63,29 @@ def build_problem(cfg, N, table):
 def cpu_baseline(cfg, N, scheme_name):
     """The reference's algorithm (oracle = NumPy/SciPy port of the numpy-compiler
     path + SuperLU) on this box's host cores: one full-size step, single thread."""
-    from oracle import corpus, numpy_path as ora
-    from triflow_amd import Model
-    name, fd, pars, dt, _ = corpus.config_inputs(cfg, N)
-    model = Model(*corpus.model_args(name), compiler=ora.numpy_compiler)
+    from oracle import numpy_path as ora          # the checker, timed as the CPU baseline
+    from triflow_amd import Model, workloads
+    name, fd, pars, dt, _ = workloads.config_inputs(cfg, N)
+    model = Model(*workloads.model_args(name), compiler=ora.numpy_compiler)
     scheme = {"ROS2": ora.ROS2, "RODASPR": lambda m: ora.RODASPR(m, time_stepping=False),
               "Theta": ora.Theta, "BDF2": ora.BDF2}[scheme_name](model)
     fields = model.fields_template(**fd)
+    nsteps, t = 3, 0.0
     t0 = time.perf_counter()
-    scheme(0.0, fields, dt, pars)
+    for _ in range(nsteps):
+        t, fields = scheme(t, fields, dt, pars)
     el = time.perf_counter() - t0
-    return dict(value=1.0 / el, unit="steps/s", cores=1, kind="port",
-                sample="1 %s step of the same workload (N=%d), NumPy %s / SciPy SuperLU, "
-                       "single thread, %.1f s" % (scheme_name, N, np.__version__, el))
+    return dict(value=nsteps / el, unit="steps/s", cores=1, kind="port",
+                sample="%d %s steps of the same workload (N=%d), NumPy %s / SciPy SuperLU, "
+                       "single thread, %.1f s" % (nsteps, scheme_name, N, np.__version__, el))
 
 
 def scheme_api_rate(model, cfg, N, scheme_name, dt, steps=20):
     """The same workload driven through the reference-style Python protocol
     ``t, fields = scheme(t, fields, dt, pars)`` with device-resident containers
     (informational; the timed region above uses the ensemble C-ABI loop)."""
-    from oracle import corpus
-    from triflow_amd import schemes
-    name, fd, pars, _, _ = corpus.config_inputs(cfg, N)
+    from triflow_amd import schemes, workloads
+    name, fd, pars, _, _ = workloads.config_inputs(cfg, N)
     scheme = {"ROS2": schemes.ROS2, "Theta": schemes.Theta, "BDF2": schemes.BDF2,
               "RODASPR": lambda m: schemes.RODASPR(m, time_stepping=False)}[scheme_name](model)
     fields, t = model.fields_template(**fd), 0.0
@@ -128,8 +129,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from oracle import corpus
-    from triflow_amd import Model
+    from triflow_amd import Model, workloads
     from triflow_amd.ensemble import Ensemble, broadcast_table, shard_members
 
     n_members = world * args.members_per_gpu
@@ -140,7 +140,7 @@ def main():
         args.config, args.nodes or None, table[mine])
     scheme = args.scheme or default_scheme
     N = x.size
-    model = Model(*corpus.model_args(name))
+    model = Model(*workloads.model_args(name))
     ens = Ensemble(model, x, fields, pars, bool(pars["periodic"]), scheme=scheme,
                    device=device_index, hook=None, nstate=2)
     solver = ens.solver
