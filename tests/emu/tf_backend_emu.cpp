@@ -83,6 +83,7 @@ void launch(Module*, int kernel, unsigned gx, unsigned gy, unsigned block,
         for (int64_t t = 0; t < nthreads; ++t) tfk_chunk_body<ROWS, -1, SP, false, false>(a, (int)t); } break;
     TF_EMU_CHUNK(TFK_L1_FACTOR, TfRowsL1, true, true, false)
     TF_EMU_CHUNK(TFK_L1_SOLVE, TfRowsL1, false, false, true)
+    TF_EMU_CHUNK(TFK_L1_FACTOR_RHS, TfRowsL1, true, true, true)
     case TFK_BT_LU: { const auto& a = *(const TfLevelArgs*)args;
         for (unsigned y = 0; y < gy; ++y) for (int64_t t = 0; t < nthreads; ++t)
             tfk_bt_lu_body<TF_B2>(a, (int)t, y == 0 ? +1 : -1); } break;

@@ -96,6 +96,12 @@ __global__ void __launch_bounds__(64) tfk_l1_factor(TfLevelArgs a) {
     if (blockIdx.y == 0) tfk_chunk_body<TfRowsL1, +1, true, true, false>(a, TF_GID);
     else tfk_chunk_body<TfRowsL1, -1, true, false, false>(a, TF_GID);
 }
+// factorisation that also eliminates a first right-hand side (the first solve of a
+// time step rides along: no second walk over J for it)
+__global__ void __launch_bounds__(64) tfk_l1_factor_rhs(TfLevelArgs a) {
+    if (blockIdx.y == 0) tfk_chunk_body<TfRowsL1, +1, true, true, true>(a, TF_GID);
+    else tfk_chunk_body<TfRowsL1, -1, true, false, false>(a, TF_GID);
+}
 __global__ void __launch_bounds__(64) tfk_l1_solve(TfLevelArgs a) {
     if (blockIdx.y == 0) tfk_chunk_body<TfRowsL1, +1, false, false, true>(a, TF_GID);
     else tfk_chunk_body<TfRowsL1, -1, false, false, false>(a, TF_GID);

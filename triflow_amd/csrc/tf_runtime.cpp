@@ -270,18 +270,24 @@ struct tf_solver {
         a.top = top_args();
         launch(TFK_TAIL, 1, 1, 256, &a, sizeof(a));
     }
-    void factor(double c) {
+    // Factorise I - c J.  With `rhs1` the first right-hand side is eliminated in the
+    // same walks (level 1: the factor kernel carries it next to the spike columns;
+    // reduced levels: one more column of the spike launch; the assemble kernels
+    // already build the next level's rhs) and `x1` receives its solution: the
+    // first solve of a time step costs only the back-substitutions.
+    void factor(double c, const double* rhs1 = nullptr, double* x1 = nullptr) {
         if (!have_jac) throw std::runtime_error("tf_factor: no Jacobian evaluated yet (call tf_eval with_j=1)");
         factor_c = c;
+        const bool fused = rhs1 != nullptr && tail_from >= levels.size();
         for (size_t l = 0; l < tail_from; ++l) {
-            TfLevelArgs a = level_args(l, nullptr, nullptr);
-            a.rhs = nullptr;
+            TfLevelArgs a = level_args(l, rhs1, x1);
+            if (!fused) a.rhs = nullptr;
             unsigned gx = cdiv(a.L.Ptot, 64);
-            if (l == 0) launch(TFK_L1_FACTOR, gx, 2, 64, &a, sizeof(a));
+            if (l == 0) launch(fused ? TFK_L1_FACTOR_RHS : TFK_L1_FACTOR, gx, 2, 64, &a, sizeof(a));
             else {
                 const unsigned gc = cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64);
                 launch(TFK_BT_LU, gc, 2, 64, &a, sizeof(a));
-                launch(TFK_BT_SPIKE, gc, 2 * (unsigned)levels[l]->B, 64, &a, sizeof(a));
+                launch(TFK_BT_SPIKE, gc, 2 * (unsigned)(levels[l]->B + (fused ? 1 : 0)), 64, &a, sizeof(a));
             }
             launch(l == 0 ? TFK_L1_ASM_MAT : TFK_BT_ASM_MAT, gx, 1, 64, &a, sizeof(a));
         }
@@ -290,6 +296,19 @@ struct tf_solver {
         have_factor = true;
         fact_checked = false;
         fact_needs_refine = false;
+        if (rhs1 == nullptr) return;
+        if (!fused) { solve(rhs1, x1); return; }
+        TfTopArgs t = top_args();
+        launch(TFK_TOP_SOLVE, cdiv(nsys, 64), 1, 64, &t, sizeof(t));
+        backsub_chain(rhs1, x1);
+        polish(rhs1, x1);
+    }
+    void backsub_chain(const double* rhs1, double* x1) {
+        for (size_t l = tail_from; l-- > 0;) {
+            TfLevelArgs a = level_args(l, rhs1, x1);
+            if (l == 0) launch(TFK_L1_BACKSUB, cdiv(a.L.Ptot, 64), 1, 64, &a, sizeof(a));
+            else launch(TFK_BT_BACKSUB, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
+        }
     }
     void solve_once(const double* rhs1, double* x1) {
         for (size_t l = 0; l < tail_from; ++l) {
@@ -301,11 +320,7 @@ struct tf_solver {
         }
         if (tail_from < levels.size()) launch_tail(false, rhs1, x1);
         else { TfTopArgs t = top_args(); launch(TFK_TOP_SOLVE, cdiv(nsys, 64), 1, 64, &t, sizeof(t)); }
-        for (size_t l = tail_from; l-- > 0;) {
-            TfLevelArgs a = level_args(l, rhs1, x1);
-            if (l == 0) launch(TFK_L1_BACKSUB, cdiv(a.L.Ptot, 64), 1, 64, &a, sizeof(a));
-            else launch(TFK_BT_BACKSUB, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
-        }
+        backsub_chain(rhs1, x1);
     }
     void refine_sweep(const double* rhs1, double* x1) {
         spmv(x1, Wjv.p, factor_c);                               // c J x
@@ -334,6 +349,9 @@ struct tf_solver {
     void solve(const double* rhs1, double* x1) {
         if (!have_factor) throw std::runtime_error("tf_solve: matrix not factorised");
         solve_once(rhs1, x1);
+        polish(rhs1, x1);
+    }
+    void polish(const double* rhs1, double* x1) {
         if (refine > 0) {
             for (int it = 0; it < refine; ++it) refine_sweep(rhs1, x1);
         } else if (refine < 0) {
@@ -685,8 +703,7 @@ int tf_step_theta(tf_solver* s, int32_t src, int32_t dst, double dt, double thet
     const double* xs[3] = {s->F.p, s->Wjv.p, U};
     const double cs[3] = {dt, 0, 0};
     s->vec(TF_VEC_THETA_RHS, s->Wrhs.p, nullptr, 3, xs, cs);       // dt*(F - .) + U
-    s->factor(theta * dt);
-    s->solve(s->Wrhs.p, s->Wstage.p);
+    s->factor(theta * dt, s->Wrhs.p, s->Wstage.p);
     const double* cp[1] = {s->Wstage.p};
     s->vec(TF_VEC_COPY, U, nullptr, 1, cp, nullptr);
     s->apply_dirichlet(U, true);
@@ -705,7 +722,6 @@ int tf_step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns,
     tfb::d2d(U, s->st(src), (size_t)s->vecn() * sizeof(double), s->stream);
     s->apply_dirichlet(U);
     s->sweep(U, true);                         // J(U) and F(U) = F of stage 0
-    s->factor(gamma[0] * dt);
     const double* ks[TF_MAX_TERMS];
     double cs[TF_MAX_TERMS];
     for (int i = 0; i < ns; ++i) {
@@ -724,7 +740,8 @@ int tf_step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns,
             const double c1[1] = {dt};
             s->vec(TF_VEC_SUM, s->Wrhs.p, nullptr, 1, xs, c1);     // dt*F
         }
-        s->solve(s->Wrhs.p, s->K[i].p);
+        if (i == 0) s->factor(gamma[0] * dt, s->Wrhs.p, s->K[0].p);   // factorise + first stage
+        else s->solve(s->Wrhs.p, s->K[i].p);
     }
     for (int j = 0; j < ns; ++j) { ks[j] = s->K[j].p; cs[j] = b[j]; }
     s->vec(TF_VEC_SUM, U, U, ns, ks, cs);                          // U + sum_i b_i k_i
@@ -763,18 +780,16 @@ int tf_step_bdf2(tf_solver* s, int32_t src, int32_t dst, double dt) {
         const double* xs[3] = {U, s->Uprev.p, s->F.p};
         const double cs[3] = {1.0 / 3.0, (2.0 / 3.0) * dt, 0};
         s->vec(TF_VEC_BDF2_RHS, s->Wrhs.p, nullptr, 3, xs, cs);
-        s->factor((2.0 / 3.0) * dt);
     } else {
         const double* xs[1] = {s->F.p};
         const double c1[1] = {dt};
         s->vec(TF_VEC_SUM, s->Wrhs.p, nullptr, 1, xs, c1);
-        s->factor(dt);
     }
     const double* cp[1] = {U};
     s->vec(TF_VEC_COPY, s->Uprev.p, nullptr, 1, cp, nullptr);
     s->bdf_have_prev = true;
     s->bdf_dt_prev = dt;
-    s->solve(s->Wrhs.p, s->Wdel.p);
+    s->factor(two_step ? (2.0 / 3.0) * dt : dt, s->Wrhs.p, s->Wdel.p);
     const double* ys[2] = {U, s->Wdel.p};
     s->vec(TF_VEC_ADD, U, nullptr, 2, ys, nullptr);
     s->apply_dirichlet(U, true);
