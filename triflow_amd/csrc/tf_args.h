@@ -39,6 +39,10 @@ struct TfSweepArgs {               // F / F+J stencil sweep, J @ v, A-row build
     double* F;                     // [nvar] planes
     double* Jv;                    // [nnz] planes (raw values, reference pattern order)
     int with_j;
+    // Rosenbrock stage state evaluated on the fly: fields + (((kc0*kx0) + kc1*kx1) + ...)
+    int nterms;
+    const double* kx[TF_MAX_TERMS];
+    double kc[TF_MAX_TERMS];
 };
 
 struct TfSpmvArgs {                // y = scale * J @ v  (clamped/wrapped columns)
@@ -48,6 +52,13 @@ struct TfSpmvArgs {                // y = scale * J @ v  (clamped/wrapped column
     double* y;                     // [nvar] planes
     double scale;
     int absval;                    // 1: y = |scale J| @ |v|  (componentwise backward error)
+    // Rosenbrock stage right-hand side in one pass: v = ((vc0*vx0) + vc1*vx1) + ...,
+    // y = cF*addF + cA*(J @ v)        (schemes.py:156-160)
+    int nterms;
+    const double* vx[TF_MAX_TERMS];
+    double vc[TF_MAX_TERMS];
+    const double* addF;
+    double cF, cA;
 };
 
 struct TfNormArgs {               // per-variable, per-system norm of (a - b): partial sums

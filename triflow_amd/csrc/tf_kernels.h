@@ -88,10 +88,13 @@ TF_DEVICE void tfk_sweep_body(const TfSweepArgs& a, int pg, int seg) {
     const double dx = a.dx[e];
 
     auto ld = [&](int f, int ii) -> double {
-        const double* plane = f < TF_NVAR ? a.fields + (int64_t)f * L.plane
-                                          : a.helpers + (int64_t)(f - TF_NVAR) * L.plane;
-        if (ii >= 0 && ii < len) return plane[tf_idx(L, pg, ii)];
-        return plane[tf_nbr(L, e, p, len, 0, ii)];
+        const int64_t s = (ii >= 0 && ii < len) ? tf_idx(L, pg, ii) : tf_nbr(L, e, p, len, 0, ii);
+        if (f >= TF_NVAR) return a.helpers[(int64_t)(f - TF_NVAR) * L.plane + s];
+        const double u = a.fields[(int64_t)f * L.plane + s];
+        if (a.nterms == 0) return u;
+        double acc = a.kc[0] * a.kx[0][(int64_t)f * L.plane + s];      // U + sum_j alpha_ij k_j
+        for (int t = 1; t < a.nterms; ++t) acc = acc + a.kc[t] * a.kx[t][(int64_t)f * L.plane + s];
+        return u + acc;
     };
 
     double w[TF_NF][TF_W];
@@ -142,9 +145,11 @@ TF_DEVICE void tfk_spmv_body(const TfSpmvArgs& a, int pg, int seg) {
     const int i0 = seg * TF_SEG;
     if (i0 >= len) return;
     auto ld = [&](int v, int ii) -> double {
-        const double* plane = a.v + (int64_t)v * L.plane;
-        if (ii >= 0 && ii < len) return plane[tf_idx(L, pg, ii)];
-        return plane[tf_nbr(L, e, p, len, 0, ii)];
+        const int64_t s = (ii >= 0 && ii < len) ? tf_idx(L, pg, ii) : tf_nbr(L, e, p, len, 0, ii);
+        if (a.nterms == 0) return a.v[(int64_t)v * L.plane + s];
+        double acc = a.vc[0] * a.vx[0][(int64_t)v * L.plane + s];       // sum_j gamma_ij k_j
+        for (int t = 1; t < a.nterms; ++t) acc = acc + a.vc[t] * a.vx[t][(int64_t)v * L.plane + s];
+        return acc;
     };
     double w[TF_NVAR][TF_W];
 #pragma unroll
@@ -173,7 +178,9 @@ TF_DEVICE void tfk_spmv_body(const TfSpmvArgs& a, int pg, int seg) {
                 acc[tf_pat_eq[k]] = acc[tf_pat_eq[k]] + jv * wv;
             }
 #pragma unroll
-            for (int v = 0; v < TF_NVAR; ++v) a.y[(int64_t)v * L.plane + s] = acc[v];
+            for (int v = 0; v < TF_NVAR; ++v)
+                a.y[(int64_t)v * L.plane + s] = a.addF
+                    ? a.cF * a.addF[(int64_t)v * L.plane + s] + a.cA * acc[v] : acc[v];
         }
     }
 }

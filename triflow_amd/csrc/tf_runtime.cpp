@@ -220,8 +220,12 @@ struct tf_solver {
         launch(TFK_DIRICHLET, cdiv((int64_t)ndir * nsys, 64), 1, 64, &a, sizeof(a));
     }
 
-    void sweep(const double* fields, bool with_j) {
+    void sweep(const double* fields, bool with_j, int nterms = 0, const double* const* kx = nullptr,
+               const double* kc = nullptr) {
         TfSweepArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.nterms = nterms;
+        for (int t = 0; t < nterms; ++t) { a.kx[t] = kx[t]; a.kc[t] = kc[t]; }
         a.L = L1; a.fields = fields; a.helpers = helpers.p; a.parvec = parvec.p; a.parsca = parsca.p;
         a.dx = dx.p; a.xcoord = xcoord.p; a.F = F.p; a.Jv = Jv.p; a.with_j = with_j ? 1 : 0;
         unsigned gx = cdiv(L1.Ptot, spec.sweep_block), gy = cdiv(L1.M, spec.seg);
@@ -230,7 +234,21 @@ struct tf_solver {
     }
     void spmv(const double* v, double* y, double scale, bool absval = false) {
         TfSpmvArgs a;
+        std::memset(&a, 0, sizeof(a));
         a.L = L1; a.Jv = Jv.p; a.v = v; a.y = y; a.scale = scale; a.absval = absval ? 1 : 0;
+        unsigned gx = cdiv(L1.Ptot, spec.sweep_block), gy = cdiv(L1.M, spec.seg);
+        launch(TFK_SPMV, gx, gy, spec.sweep_block, &a, sizeof(a));
+    }
+
+    // y = cF*F + cA*(J @ sum_t vc_t vx_t): stage right-hand side of a ROW scheme in one pass
+    void spmv_stage(int nterms, const double* const* vx, const double* vc, const double* Fp,
+                    double cF, double cA, double* y) {
+        TfSpmvArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.L = L1; a.Jv = Jv.p; a.v = nullptr; a.y = y; a.scale = 1.0;
+        a.nterms = nterms;
+        for (int t = 0; t < nterms; ++t) { a.vx[t] = vx[t]; a.vc[t] = vc[t]; }
+        a.addF = Fp; a.cF = cF; a.cA = cA;
         unsigned gx = cdiv(L1.Ptot, spec.sweep_block), gy = cdiv(L1.M, spec.seg);
         launch(TFK_SPMV, gx, gy, spec.sweep_block, &a, sizeof(a));
     }
@@ -726,15 +744,12 @@ int tf_step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns,
     double cs[TF_MAX_TERMS];
     for (int i = 0; i < ns; ++i) {
         if (i > 0) {
+            // F(U + sum_j alpha_ij k_j): the stage state is formed inside the sweep
             for (int j = 0; j < i; ++j) { ks[j] = s->K[j].p; cs[j] = alpha[i * ns + j]; }
-            s->vec(TF_VEC_SUM, s->Wstage.p, U, i, ks, cs);         // U + sum_j alpha_ij k_j
-            s->sweep(s->Wstage.p, false);
+            s->sweep(U, false, i, ks, cs);
+            // dt*F + dt*(J @ sum_j gamma_ij k_j) in one pass over J
             for (int j = 0; j < i; ++j) cs[j] = gamma[i * ns + j];
-            s->vec(TF_VEC_SUM, s->Wsum.p, nullptr, i, ks, cs);     // sum_j gamma_ij k_j
-            s->spmv(s->Wsum.p, s->Wjv.p, 1.0);
-            const double* xs[2] = {s->F.p, s->Wjv.p};
-            const double c2[2] = {dt, dt};
-            s->vec(TF_VEC_LIN2, s->Wrhs.p, nullptr, 2, xs, c2);    // dt*F + dt*(J @ .)
+            s->spmv_stage(i, ks, cs, s->F.p, dt, dt, s->Wrhs.p);
         } else {
             const double* xs[1] = {s->F.p};
             const double c1[1] = {dt};
