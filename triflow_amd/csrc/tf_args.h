@@ -165,10 +165,10 @@ enum TfKernel {
     TFK_SWEEP_F = 0, TFK_SWEEP_FJ, TFK_SPMV, TFK_VEC, TFK_VEC_MAXABS, TFK_PERM, TFK_DIRICHLET,
     TFK_L1_FACTOR, TFK_L1_SOLVE, TFK_L1_ASM_MAT, TFK_L1_ASM_RHS, TFK_L1_BACKSUB,
     TFK_BT_LU, TFK_BT_SPIKE, TFK_BT_RHS, TFK_BT_ASM_MAT, TFK_BT_ASM_RHS, TFK_BT_BACKSUB,
-    TFK_TOP_FACTOR, TFK_TOP_SOLVE, TFK_BERR, TFK_TAIL, TFK_DIFFNORM, TFK_L1_FACTOR_RHS, TFK_COUNT
+    TFK_TOP_FACTOR, TFK_TOP_SOLVE, TFK_BERR, TFK_TAIL, TFK_DIFFNORM, TFK_L1_FACTOR_RHS, TFK_SWEEP_F_STAGE, TFK_COUNT
 };
 #define TF_KERNEL_NAMES { \
     "tfk_sweep_f", "tfk_sweep_fj", "tfk_spmv", "tfk_vec", "tfk_vec_maxabs", "tfk_perm", "tfk_dirichlet", \
     "tfk_l1_factor", "tfk_l1_solve", "tfk_l1_asm_mat", "tfk_l1_asm_rhs", "tfk_l1_backsub", \
     "tfk_bt_lu", "tfk_bt_spike", "tfk_bt_rhs", "tfk_bt_asm_mat", "tfk_bt_asm_rhs", "tfk_bt_backsub", \
-    "tfk_top_factor", "tfk_top_solve", "tfk_berr", "tfk_tail", "tfk_diffnorm", "tfk_l1_factor_rhs" }
+    "tfk_top_factor", "tfk_top_solve", "tfk_berr", "tfk_tail", "tfk_diffnorm", "tfk_l1_factor_rhs", "tfk_sweep_f_stage" }

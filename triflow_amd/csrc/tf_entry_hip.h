@@ -14,6 +14,10 @@ extern "C" {
 __global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_sweep_f(TfSweepArgs a) {
     tfk_sweep_body<false>(a, TF_GID, blockIdx.y);
 }
+// F at a Rosenbrock stage state U + sum_j alpha_ij k_j formed while loading
+__global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_sweep_f_stage(TfSweepArgs a) {
+    tfk_sweep_body<false, true>(a, TF_GID, blockIdx.y);
+}
 __global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_sweep_fj(TfSweepArgs a) {
     tfk_sweep_body<true>(a, TF_GID, blockIdx.y);
 }

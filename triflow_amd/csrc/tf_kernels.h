@@ -72,7 +72,7 @@ TF_DEVICE void tf_locate(const TfLayout& L, int g, int& p, int& i) {
 // 1. F / F+J stencil sweep                       (compilers.py:227-332)
 // ===========================================================================
 // grid: x over chunks (all systems), y over segments of TF_SEG nodes.
-template <bool WITH_J>
+template <bool WITH_J, bool STAGE = false>
 TF_DEVICE void tfk_sweep_body(const TfSweepArgs& a, int pg, int seg) {
     const TfLayout& L = a.L;
     if (pg >= L.Ptot) return;
@@ -91,7 +91,7 @@ TF_DEVICE void tfk_sweep_body(const TfSweepArgs& a, int pg, int seg) {
         const int64_t s = (ii >= 0 && ii < len) ? tf_idx(L, pg, ii) : tf_nbr(L, e, p, len, 0, ii);
         if (f >= TF_NVAR) return a.helpers[(int64_t)(f - TF_NVAR) * L.plane + s];
         const double u = a.fields[(int64_t)f * L.plane + s];
-        if (a.nterms == 0) return u;
+        if (!STAGE) return u;
         double acc = a.kc[0] * a.kx[0][(int64_t)f * L.plane + s];      // U + sum_j alpha_ij k_j
         for (int t = 1; t < a.nterms; ++t) acc = acc + a.kc[t] * a.kx[t][(int64_t)f * L.plane + s];
         return u + acc;

@@ -229,7 +229,9 @@ struct tf_solver {
         a.L = L1; a.fields = fields; a.helpers = helpers.p; a.parvec = parvec.p; a.parsca = parsca.p;
         a.dx = dx.p; a.xcoord = xcoord.p; a.F = F.p; a.Jv = Jv.p; a.with_j = with_j ? 1 : 0;
         unsigned gx = cdiv(L1.Ptot, spec.sweep_block), gy = cdiv(L1.M, spec.seg);
-        launch(with_j ? TFK_SWEEP_FJ : TFK_SWEEP_F, gx, gy, spec.sweep_block, &a, sizeof(a));
+        if (nterms > 0 && with_j) throw std::logic_error("stage sweep evaluates F only");
+        launch(with_j ? TFK_SWEEP_FJ : (nterms > 0 ? TFK_SWEEP_F_STAGE : TFK_SWEEP_F), gx, gy,
+               spec.sweep_block, &a, sizeof(a));
         if (with_j) { have_jac = true; have_factor = false; }
     }
     void spmv(const double* v, double* y, double scale, bool absval = false) {
