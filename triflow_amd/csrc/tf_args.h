@@ -138,6 +138,9 @@ struct TfLevelArgs {
     double* rhsnext;
     const double* xnext;
     int* status;                   // != 0 when a pivot block was singular / non-finite
+    // cooperative reduced-level LU: also eliminate this many columns (b spike columns,
+    // +1 for a right-hand side) in the same walk; 0 = the separate column kernel does it
+    int lu_cols;
 };
 
 struct TfTopArgs {                 // final 1-node system per ensemble member

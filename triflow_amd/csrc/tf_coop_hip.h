@@ -42,8 +42,11 @@ __device__ __forceinline__ void tfk_bt_lu_coop(const TfLevelArgs& a, int dir) {
     __shared__ double sAh[NGRP][BB][BB];
     __shared__ double sRow[NGRP][2 * BB];
     __shared__ double sAbs[2][NGRP][G];
+    __shared__ double sE[NGRP][BB][BB + 1];          // spike / rhs columns: en of the previous node
+    __shared__ double sV[NGRP][BB][BB + 1];          //                      ev of this node
+    const int ncols = a.lu_cols;                     // 0, BB or BB + 1
 
-    struct Row { double dia[BB], ah[BB], bh[BB]; };
+    struct Row { double dia[BB], ah[BB], bh[BB], rhs; };
     auto load = [&](int j, Row& r) {
         const int i = dir > 0 ? j : mI - 1 - j;
         const int64_t s = tf_idx(L, pg, i);
@@ -56,13 +59,16 @@ __device__ __forceinline__ void tfk_bt_lu_coop(const TfLevelArgs& a, int dir) {
             r.ah[c] = cut_a ? 0.0 : a.Ablk[(int64_t)((ahead * BB + g) * BB + c) * L.plane + s];
             r.bh[c] = cut_b ? 0.0 : a.Ablk[(int64_t)((behind * BB + g) * BB + c) * L.plane + s];
         }
+        r.rhs = ncols > BB ? a.rhs[(int64_t)g * L.plane + s] : 0.0;
     };
     Row cur, nxt;
     if (lane_on && mI > 0) load(0, cur);
 
-    double S[BB], INV[BB], AHlast[BB];
+    double S[BB], INV[BB], AHlast[BB], ENlast[BB + 1];
 #pragma unroll
     for (int c = 0; c < BB; ++c) AHlast[c] = 0.0;
+#pragma unroll
+    for (int c = 0; c <= BB; ++c) ENlast[c] = 0.0;
     bool ok = true;
     int myk_last = 0;
     const int rounds = L.M - 1;                      // uniform over the block
@@ -135,6 +141,41 @@ __device__ __forceinline__ void tfk_bt_lu_coop(const TfLevelArgs& a, int dir) {
             }
             myk_last = myk;
         }
+        if (ncols > 0) {
+            // ---- the spike columns (and the rhs) through this node, as tfk_bt_col_body does:
+            //      ev = v - behind * en_prev,  en = Dinv * ev
+            if (on) {
+#pragma unroll
+                for (int col = 0; col <= BB; ++col) {
+                    if (col < ncols) {
+                        double ev = col < BB ? (j == 0 ? cur.bh[col] : 0.0) : cur.rhs;
+                        if (j > 0) {
+#pragma unroll
+                            for (int k = 0; k < BB; ++k) ev = tf_fma(-cur.bh[k], sE[grp][k][col], ev);
+                        }
+                        sV[grp][g][col] = ev;
+                    }
+                }
+            }
+            __syncthreads();
+            if (on) {
+                const int64_t s = tf_idx(L, pg, dir > 0 ? j : mI - 1 - j);
+#pragma unroll
+                for (int col = 0; col <= BB; ++col) {
+                    if (col < ncols) {
+                        double en = 0.0;
+#pragma unroll
+                        for (int k = 0; k < BB; ++k) en = tf_fma(INV[k], sV[grp][k][col], en);
+                        sE[grp][myk][col] = en;
+                        ENlast[col] = en;
+                        if (dir > 0) {
+                            if (col < BB) a.Et[(int64_t)(myk * BB + col) * L.plane + s] = en;
+                            else a.yt[(int64_t)myk * L.plane + s] = en;
+                        }
+                    }
+                }
+            }
+        }
         __syncthreads();
         cur = nxt;
     }
@@ -144,6 +185,13 @@ __device__ __forceinline__ void tfk_bt_lu_coop(const TfLevelArgs& a, int dir) {
 #pragma unroll
         for (int c = 0; c < BB; ++c)
             tips[(int64_t)(dir > 0 ? Tip::W(0, 0, myk_last, c) : Tip::V(0, 0, myk_last, c)) * L.Ptot + pg] = AHlast[c];
+#pragma unroll
+        for (int col = 0; col <= BB; ++col)
+            if (col < ncols) {
+                const int slot = col >= BB ? Tip::y(0, myk_last)
+                    : (dir > 0 ? Tip::V(0, 0, myk_last, col) : Tip::W(0, 0, myk_last, col));
+                tips[(int64_t)slot * L.Ptot + pg] = ENlast[col];
+            }
     }
     if (!ok && lane_on) *a.status = 1;
 }
@@ -279,5 +327,69 @@ __device__ __forceinline__ void tfk_bt_backsub_coop(const TfLevelArgs& a) {
         }
         __syncthreads();
         cur = nxt;
+    }
+}
+
+// ---- interface equations of a reduced level: one lane per (separator, block row) ----
+// Row g of  [sub | dia | sup | rhs]  of the next level (tfk_asm_body for MP = 1), same
+// accumulation order; no exchange between the lanes of a group is needed.
+template <int BB, bool MATRIX>
+__device__ __forceinline__ void tfk_bt_asm_coop(const TfLevelArgs& a) {
+    typedef TfTips<BB, 1> Tip;
+    constexpr int G = TfCoop<BB>::G;
+    const TfLayout& L = a.L;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pg = gid / G, g = gid % G;
+    if (pg >= L.Ptot || g >= BB) return;
+    const int e = pg / L.P, p = pg - e * L.P;
+    const int len = tf_len(L, p), mI = len - 1, start = tf_start(L, p);
+    const bool has_next = L.periodic || p < L.P - 1;
+    const int pn = e * L.P + (p < L.P - 1 ? p + 1 : 0);
+    const int gn = start + mI;                               // the separator node
+    const bool cut_sub = !L.periodic && gn == 0, cut_sup = !L.periodic && gn == L.N - 1;
+    const int64_t s = tf_idx(L, pg, mI);
+    int p2, i2;
+    tf_locate(a.Lnext, p, p2, i2);
+    const int64_t s2 = tf_idx(a.Lnext, e * a.Lnext.P + p2, i2);
+    auto tdn = [&](int slot) { return a.tips_dn[(int64_t)slot * L.Ptot + pg]; };
+    auto tup = [&](int slot) { return a.tips_up[(int64_t)slot * L.Ptot + pn]; };
+
+    double H[BB], D[BB], K[BB];
+#pragma unroll
+    for (int c = 0; c < BB; ++c) {
+        H[c] = cut_sub ? 0.0 : a.Ablk[(int64_t)((0 * BB + g) * BB + c) * L.plane + s];
+        D[c] = a.Ablk[(int64_t)((1 * BB + g) * BB + c) * L.plane + s];
+        K[c] = cut_sup ? 0.0 : a.Ablk[(int64_t)((2 * BB + g) * BB + c) * L.plane + s];
+    }
+    // right-hand side:  g - H * yb - K * yt(next)
+    double rg = a.rhs ? a.rhs[(int64_t)g * L.plane + s] : 0.0;
+#pragma unroll
+    for (int k = 0; k < BB; ++k) rg = tf_fma(-H[k], tdn(Tip::y(0, k)), rg);
+    if (has_next) {
+#pragma unroll
+        for (int k = 0; k < BB; ++k) rg = tf_fma(-K[k], tup(Tip::y(0, k)), rg);
+    }
+    a.rhsnext[(int64_t)g * a.Lnext.plane + s2] = rg;
+    if (MATRIX) {
+#pragma unroll
+        for (int c = 0; c < BB; ++c) {
+            double sub = 0.0, dia = 0.0, sup = 0.0;
+#pragma unroll
+            for (int k = 0; k < BB; ++k) {
+                sub = tf_fma(-H[k], tdn(Tip::V(0, 0, k, c)), sub);
+                dia = tf_fma(-H[k], tdn(Tip::W(0, 0, k, c)), dia);
+            }
+            dia += D[c];
+            if (has_next) {
+#pragma unroll
+                for (int k = 0; k < BB; ++k) {
+                    dia = tf_fma(-K[k], tup(Tip::V(0, 0, k, c)), dia);
+                    sup = tf_fma(-K[k], tup(Tip::W(0, 0, k, c)), sup);
+                }
+            }
+            a.Anext[(int64_t)((0 * BB + g) * BB + c) * a.Lnext.plane + s2] = sub;
+            a.Anext[(int64_t)((1 * BB + g) * BB + c) * a.Lnext.plane + s2] = dia;
+            a.Anext[(int64_t)((2 * BB + g) * BB + c) * a.Lnext.plane + s2] = sup;
+        }
     }
 }

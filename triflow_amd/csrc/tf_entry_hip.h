@@ -132,8 +132,14 @@ __global__ void __launch_bounds__(64) tfk_bt_rhs(TfLevelArgs a) {
     if constexpr (TfCoop<TF_B2>::G > 1) tfk_bt_col_coop<TF_B2>(a, blockIdx.y == 0 ? +1 : -1, TF_B2);
     else tfk_bt_col_body<TF_B2>(a, TF_GID, blockIdx.y == 0 ? +1 : -1, TF_B2);
 }
-__global__ void __launch_bounds__(64) tfk_bt_asm_mat(TfLevelArgs a) { tfk_asm_body<TfRowsUp, true>(a, TF_GID); }
-__global__ void __launch_bounds__(64) tfk_bt_asm_rhs(TfLevelArgs a) { tfk_asm_body<TfRowsUp, false>(a, TF_GID); }
+__global__ void __launch_bounds__(64) tfk_bt_asm_mat(TfLevelArgs a) {
+    if constexpr (TfCoop<TF_B2>::G > 1) tfk_bt_asm_coop<TF_B2, true>(a);
+    else tfk_asm_body<TfRowsUp, true>(a, TF_GID);
+}
+__global__ void __launch_bounds__(64) tfk_bt_asm_rhs(TfLevelArgs a) {
+    if constexpr (TfCoop<TF_B2>::G > 1) tfk_bt_asm_coop<TF_B2, false>(a);
+    else tfk_asm_body<TfRowsUp, false>(a, TF_GID);
+}
 __global__ void __launch_bounds__(64) tfk_bt_backsub(TfLevelArgs a) {
     if constexpr (TfCoop<TF_B2>::G > 1) tfk_bt_backsub_coop<TF_B2>(a);
     else tfk_backsub_body<TfRowsUp>(a, TF_GID);

@@ -305,11 +305,15 @@ struct tf_solver {
             unsigned gx = cdiv(a.L.Ptot, 64);
             if (l == 0) launch(fused ? TFK_L1_FACTOR_RHS : TFK_L1_FACTOR, gx, 2, 64, &a, sizeof(a));
             else {
-                const unsigned gc = cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64);
+                const int G = tfb::coop_group(levels[l]->B);
+                const unsigned gc = cdiv((int64_t)a.L.Ptot * G, 64);
+                const int ncols = levels[l]->B + (fused ? 1 : 0);
+                a.lu_cols = G > 1 ? ncols : 0;        // the cooperative LU walks the columns itself
                 launch(TFK_BT_LU, gc, 2, 64, &a, sizeof(a));
-                launch(TFK_BT_SPIKE, gc, 2 * (unsigned)(levels[l]->B + (fused ? 1 : 0)), 64, &a, sizeof(a));
+                if (G == 1) launch(TFK_BT_SPIKE, gc, 2 * (unsigned)ncols, 64, &a, sizeof(a));
             }
-            launch(l == 0 ? TFK_L1_ASM_MAT : TFK_BT_ASM_MAT, gx, 1, 64, &a, sizeof(a));
+            if (l == 0) launch(TFK_L1_ASM_MAT, gx, 1, 64, &a, sizeof(a));
+            else launch(TFK_BT_ASM_MAT, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
         }
         if (tail_from < levels.size()) launch_tail(true, nullptr, nullptr);
         else { TfTopArgs t = top_args(); launch(TFK_TOP_FACTOR, cdiv(nsys, 64), 1, 64, &t, sizeof(t)); }
@@ -336,7 +340,8 @@ struct tf_solver {
             unsigned gx = cdiv(a.L.Ptot, 64);
             if (l == 0) launch(TFK_L1_SOLVE, gx, 2, 64, &a, sizeof(a));
             else launch(TFK_BT_RHS, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 2, 64, &a, sizeof(a));
-            launch(l == 0 ? TFK_L1_ASM_RHS : TFK_BT_ASM_RHS, gx, 1, 64, &a, sizeof(a));
+            if (l == 0) launch(TFK_L1_ASM_RHS, gx, 1, 64, &a, sizeof(a));
+            else launch(TFK_BT_ASM_RHS, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
         }
         if (tail_from < levels.size()) launch_tail(false, rhs1, x1);
         else { TfTopArgs t = top_args(); launch(TFK_TOP_SOLVE, cdiv(nsys, 64), 1, 64, &t, sizeof(t)); }
@@ -440,7 +445,7 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
     std::unique_ptr<tf_solver> s(new tf_solver());
     s->model = model; s->spec = sp; s->N = N; s->nsys = nsys; s->periodic = periodic ? 1 : 0;
     int m1 = opts && opts->m1 > 0 ? opts->m1 : 32;
-    int mup = opts && opts->m_upper > 0 ? opts->m_upper : 8;
+    int mup = opts && opts->m_upper > 0 ? opts->m_upper : 6;
     s->nstate = opts && opts->nstate > 0 ? opts->nstate : 3;
     s->refine = opts ? opts->refine : -1;      // 0 = never, n > 0 = fixed sweeps, -1 = auto
     if (opts && opts->device >= 0) tfb::set_device(opts->device);
