@@ -105,6 +105,12 @@ struct tf_solver {
     bool have_factor = false, have_jac = false;
     bool fact_checked = false, fact_needs_refine = false;   // refine == -1 (auto)
     double last_omega = 0.0, refine_trigger = 1e-10;
+    // the backward-error check is a monitor: every factorisation while the matrix is new
+    // (first 4, or c changed by > 10 %), then every berr_every-th one
+    int berr_every = 8;
+    int64_t n_factor = 0, last_checked = -1000;
+    double checked_c = 0.0;
+    bool check_now = true;
 
     // declarative Dirichlet hook
     int ndir = 0;
@@ -318,8 +324,11 @@ struct tf_solver {
         if (tail_from < levels.size()) launch_tail(true, nullptr, nullptr);
         else { TfTopArgs t = top_args(); launch(TFK_TOP_FACTOR, cdiv(nsys, 64), 1, 64, &t, sizeof(t)); }
         have_factor = true;
-        fact_checked = false;
-        fact_needs_refine = false;
+        ++n_factor;
+        const bool c_moved = std::fabs(c - checked_c) > 0.1 * std::fabs(checked_c);
+        check_now = n_factor <= 4 || c_moved || n_factor - last_checked >= berr_every;
+        if (check_now) { fact_checked = false; fact_needs_refine = false; }
+        // (between checks the verdict of the last checked factorisation stands)
         if (rhs1 == nullptr) return;
         if (!fused) { solve(rhs1, x1); return; }
         TfTopArgs t = top_args();
@@ -383,6 +392,8 @@ struct tf_solver {
             if (!fact_checked) {
                 last_omega = backward_error(rhs1, x1);
                 fact_checked = true;
+                last_checked = n_factor;
+                checked_c = factor_c;
                 fact_needs_refine = !(last_omega <= refine_trigger);
             }
             if (fact_needs_refine) {
@@ -448,6 +459,7 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
     int mup = opts && opts->m_upper > 0 ? opts->m_upper : 6;
     s->nstate = opts && opts->nstate > 0 ? opts->nstate : 3;
     s->refine = opts ? opts->refine : -1;      // 0 = never, n > 0 = fixed sweeps, -1 = auto
+    if (opts && opts->berr_every > 0) s->berr_every = opts->berr_every;
     if (opts && opts->device >= 0) tfb::set_device(opts->device);
     m1 = std::max(m1, 2 * sp.mp);
     mup = std::max(mup, 2);
