@@ -401,3 +401,41 @@ def check_notebook_model(name, backend):
             t, f_o = so(t, f_o, dt, pars)
         err = np.abs(f_d.uflat - f_o.uflat).max() / np.abs(f_o.uflat).max()
         assert err <= 1e-9, (name, err)
+
+
+def check_simulation_stays_resident(backend):
+    """README-style run with a declarative hook: the state is uploaded once and only
+    downloaded when the user reads it (here: once, at the end)."""
+    from triflow_amd import _capi
+    m = device_model("M1_advdiff", backend)
+    _, fdict, pars, dt, _ = corpus.config_inputs(1, 200)
+    counts = dict(up=0, down=0)
+    orig_set, orig_get = _capi.DeviceSolver.set_state, _capi.DeviceSolver.get_state
+
+    def set_state(self, *a, **k):
+        counts["up"] += 1
+        return orig_set(self, *a, **k)
+
+    def get_state(self, *a, **k):
+        counts["down"] += 1
+        return orig_get(self, *a, **k)
+    _capi.DeviceSolver.set_state, _capi.DeviceSolver.get_state = set_state, get_state
+    try:
+        sim = Simulation(m, fdict, pars, dt, hook=DEVICE_HOOKS["cfg1"], tmax=2.5,
+                         scheme=schemes.Theta, time_stepping=False)
+        for t, fields in sim:
+            pass
+        assert counts == dict(up=1, down=0), counts
+        U = fields.uflat
+        assert counts == dict(up=1, down=1), counts
+        for ts in (True,):
+            sim = Simulation(m, fdict, pars, dt, hook=DEVICE_HOOKS["cfg1"], tmax=2.5,
+                             scheme=schemes.ROS2, time_stepping=ts)
+            before = dict(counts)
+            for t, fields in sim:
+                pass
+            assert counts["down"] == before["down"], counts      # norms reduced on the device
+    finally:
+        _capi.DeviceSolver.set_state, _capi.DeviceSolver.get_state = orig_set, orig_get
+    g = np.load(os.path.join(GOLDEN, "simulation.npz"))
+    assert np.abs(U - g["Theta_ts0_U"][-1]).max() <= 1e-10

@@ -81,3 +81,7 @@ def test_time_dependent_hook(backend):
 @pytest.mark.parametrize("name", sorted(pc.NOTEBOOK_CASES))
 def test_notebook_models(name, backend):
     pc.check_notebook_model(name, backend)
+
+
+def test_simulation_stays_resident(backend):
+    pc.check_simulation_stays_resident(backend)

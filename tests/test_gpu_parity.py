@@ -208,3 +208,7 @@ def test_config_steps_vs_oracle(cfg, N, nsteps, tol):
 @pytest.mark.parametrize("name", sorted(pc.NOTEBOOK_CASES))
 def test_notebook_models(name):
     pc.check_notebook_model(name, HIP)
+
+
+def test_simulation_stays_resident():
+    pc.check_simulation_stays_resident(HIP)

@@ -100,7 +100,7 @@ class DeviceBacking:
 
 
 class Stepper:
-    def __init__(self, compiled, N, periodic, parvec_mask, nstate=4, **opts):
+    def __init__(self, compiled, N, periodic, parvec_mask, nstate=6, **opts):
         self.compiled = compiled
         self.solver = compiled.solver(N, periodic, 1, parvec_mask, nstate=nstate, **opts)
         self.nstate = nstate

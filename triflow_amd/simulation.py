@@ -34,7 +34,7 @@ from uuid import uuid1
 from numpy import isclose
 
 from . import schemes
-from .device import null_hook
+from .device import DirichletHook, null_hook
 
 log = logging.getLogger(__name__)
 log.addHandler(logging.NullHandler())
@@ -103,7 +103,13 @@ class Simulation:
         self._iterator = self.compute()
 
     def _compute_one_step(self, t, fields, pars):
-        fields, pars = self._hook(t, fields, pars)
+        if isinstance(self._hook, DirichletHook):
+            # the reference calls hook here and again as the first action of the scheme
+            # (simulation.py:214, schemes.py:145,549); a declarative hook is idempotent, so
+            # only its parameter update is taken here and the fields stay on the GPU
+            pars = self._hook.update_pars(t, pars)
+        else:
+            fields, pars = self._hook(t, fields, pars)
         self.dt = (self.tmax - t if self.tmax and (t + self.dt >= self.tmax) else self.dt)
         before = time.perf_counter()
         t, fields = self._scheme(t, fields, self.dt, pars, hook=self._hook)
