@@ -40,8 +40,7 @@ __device__ __forceinline__ void tfk_bt_lu_coop(const TfLevelArgs& a, int dir) {
 
     __shared__ double sUn[NGRP][BB][BB];
     __shared__ double sAh[NGRP][BB][BB];
-    __shared__ double sRow[NGRP][2 * BB];
-    __shared__ double sAbs[2][NGRP][G];
+    __shared__ double sAll[2][NGRP][G][2 * BB + 1];   // every lane's row [S | INV | |S[k]|], double buffered
     __shared__ double sE[NGRP][BB][BB + 1];          // spike / rhs columns: en of the previous node
     __shared__ double sV[NGRP][BB][BB + 1];          //                      ev of this node
     const int ncols = a.lu_cols;                     // 0, BB or BB + 1
@@ -89,41 +88,44 @@ __device__ __forceinline__ void tfk_bt_lu_coop(const TfLevelArgs& a, int dir) {
             }
         }
         int myk = -1;                                // pivot index this lane ended up serving
-        sAbs[0][grp][g] = on ? tf_abs(S[0]) : -1.0;
+        // Before each pivot every lane publishes its current row and its candidate
+        // magnitude; after ONE barrier everybody knows the pivot lane and has its row.
+        auto publish = [&](int k) {
+            double* dst = sAll[k & 1][grp][g];
+#pragma unroll
+            for (int c = 0; c < BB; ++c) { dst[c] = S[c]; dst[BB + c] = INV[c]; }
+            dst[2 * BB] = (on && myk < 0 && g < BB) ? tf_abs(S[k]) : -1.0;
+        };
+        publish(0);
         __syncthreads();                             // also: everybody has read sUn
 #pragma unroll
         for (int k = 0; k < BB; ++k) {
-            // ---- pivot lane: largest |S[.][k]| among unused lanes (first on ties)
             int piv = 0;
             double best = -2.0;
 #pragma unroll
-            for (int r = 0; r < BB; ++r) {
-                const double v = sAbs[k & 1][grp][r];
+            for (int r = 0; r < BB; ++r) {           // largest |S[.][k]| among unused lanes (first on ties)
+                const double v = sAll[k & 1][grp][r][2 * BB];
                 if (v > best) { best = v; piv = r; }
             }
-            if (on && g == piv) {
-                myk = k;
-#pragma unroll
-                for (int c = 0; c < BB; ++c) { sRow[grp][c] = S[c]; sRow[grp][BB + c] = INV[c]; }
-            }
-            __syncthreads();
             if (on) {
-                const double pv = sRow[grp][k];
+                const double* prow = sAll[k & 1][grp][piv];
+                const double pv = prow[k];
                 ok = ok && (pv != 0.0) && tf_finite(pv);
                 const double rp = 1.0 / pv;
                 if (g == piv) {
+                    myk = k;
 #pragma unroll
                     for (int c = 0; c < BB; ++c) { S[c] *= rp; INV[c] *= rp; }
                 } else {
                     const double f = S[k];
 #pragma unroll
                     for (int c = 0; c < BB; ++c) {
-                        S[c] = tf_fma(-f, sRow[grp][c] * rp, S[c]);
-                        INV[c] = tf_fma(-f, sRow[grp][BB + c] * rp, INV[c]);
+                        S[c] = tf_fma(-f, prow[c] * rp, S[c]);
+                        INV[c] = tf_fma(-f, prow[BB + c] * rp, INV[c]);
                     }
                 }
             }
-            if (k + 1 < BB) sAbs[(k + 1) & 1][grp][g] = (on && myk < 0) ? tf_abs(S[k + 1]) : -1.0;
+            if (k + 1 < BB) publish(k + 1);
             __syncthreads();
         }
         if (on) {                                    // INV = row myk of S^-1;  Un = S^-1 * ahead
