@@ -439,3 +439,30 @@ def check_simulation_stays_resident(backend):
         _capi.DeviceSolver.set_state, _capi.DeviceSolver.get_state = orig_set, orig_get
     g = np.load(os.path.join(GOLDEN, "simulation.npz"))
     assert np.abs(U - g["Theta_ts0_U"][-1]).max() <= 1e-10
+
+
+def check_unstable_factorisation_is_loud(backend):
+    """A plan on which block elimination without pivoting across nodes breaks down
+    (dispersive scalar equation, 4-node chunks) must raise, not return a wrong
+    solution; the default plan solves the same system."""
+    import pytest
+    name, N, c = "kdv", 203, 0.1
+    m, mo = device_model(name, backend), oracle_model(name)
+    fd = corpus.synthetic_fields(name, N, seed=7, periodic=True, length=N * 5e-3)
+    pars = corpus.synthetic_pars(name, N, True)
+    Jo = mo.J(mo.fields_template(**fd), pars)
+    A = sps.identity(N, format="csc") - c * Jo
+    rhs = np.random.default_rng(5).standard_normal(N)
+    xs = spla.spsolve(A, rhs)
+    bad = bound_solver(m, fd, pars, m1=4, m_upper=2)
+    bad.eval(0, with_j=True)
+    bad.factor(c)
+    with pytest.raises(RuntimeError, match="lost accuracy"):
+        bad.solve(rhs)
+    good = bound_solver(m, fd, pars)
+    good.eval(0, with_j=True)
+    good.factor(c)
+    x = good.solve(rhs)[0]
+    assert np.abs(x - xs).max() <= 1e-9 * np.abs(xs).max()
+    omega, refined = good.backward_error()
+    assert refined and omega < 1e-10

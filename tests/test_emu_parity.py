@@ -85,3 +85,7 @@ def test_notebook_models(name, backend):
 
 def test_simulation_stays_resident(backend):
     pc.check_simulation_stays_resident(backend)
+
+
+def test_unstable_factorisation_is_loud(backend):
+    pc.check_unstable_factorisation_is_loud(backend)

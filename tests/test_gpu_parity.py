@@ -212,3 +212,7 @@ def test_notebook_models(name):
 
 def test_simulation_stays_resident():
     pc.check_simulation_stays_resident(HIP)
+
+
+def test_unstable_factorisation_is_loud():
+    pc.check_unstable_factorisation_is_loud(HIP)

@@ -327,7 +327,7 @@ struct tf_solver {
         ++n_factor;
         const bool c_moved = std::fabs(c - checked_c) > 0.1 * std::fabs(checked_c);
         check_now = n_factor <= 4 || c_moved || n_factor - last_checked >= berr_every;
-        if (check_now) { fact_checked = false; fact_needs_refine = false; }
+        if (check_now) { fact_checked = false; fact_needs_refine = false; sweeps_needed = 0; }
         // (between checks the verdict of the last checked factorisation stands)
         if (rhs1 == nullptr) return;
         if (!fused) { solve(rhs1, x1); return; }
@@ -385,6 +385,13 @@ struct tf_solver {
         solve_once(rhs1, x1);
         polish(rhs1, x1);
     }
+    // refine > 0: that many sweeps.  refine < 0 (default): on a *checked* solve the
+    // backward error is measured; above the trigger, sweeps are added (at most 6) until
+    // it is met, and later solves with the same factorisation repeat that number of
+    // sweeps.  A factorisation that cannot be polished below 1e-6 is an error: the
+    // elimination broke down (no pivoting across blocks), better loud than wrong.
+    int sweeps_needed = 0;
+    bool unstable = false;
     void polish(const double* rhs1, double* x1) {
         if (refine > 0) {
             for (int it = 0; it < refine; ++it) refine_sweep(rhs1, x1);
@@ -394,11 +401,22 @@ struct tf_solver {
                 fact_checked = true;
                 last_checked = n_factor;
                 checked_c = factor_c;
-                fact_needs_refine = !(last_omega <= refine_trigger);
-            }
-            if (fact_needs_refine) {
-                refine_sweep(rhs1, x1);
-                refine_sweep(rhs1, x1);
+                sweeps_needed = 0;
+                if (!(last_omega <= refine_trigger)) {
+                    // polish down to 1e-13 (or until it stops improving), at most 6 sweeps
+                    double prev = last_omega;
+                    while (sweeps_needed < 6 && !(last_omega <= 1e-13)) {
+                        refine_sweep(rhs1, x1);
+                        ++sweeps_needed;
+                        last_omega = backward_error(rhs1, x1);
+                        if (!(last_omega < 0.5 * prev)) break;
+                        prev = last_omega;
+                    }
+                }
+                fact_needs_refine = sweeps_needed > 0;
+                if (!(last_omega <= 1e-6)) unstable = true;
+            } else {
+                for (int it = 0; it < sweeps_needed; ++it) refine_sweep(rhs1, x1);
             }
         }
     }
@@ -409,6 +427,11 @@ struct tf_solver {
         if (flag != 0) {
             tfb::memset0(status, sizeof(int), stream);
             throw std::runtime_error("banded solver: singular or non-finite pivot block");
+        }
+        if (unstable) {
+            unstable = false;
+            throw std::runtime_error("banded solver: the block elimination lost accuracy (backward error " +
+                                     std::to_string(last_omega) + " after refinement); no pivoting across blocks");
         }
     }
 };
