@@ -89,3 +89,7 @@ def test_simulation_stays_resident(backend):
 
 def test_unstable_factorisation_is_loud(backend):
     pc.check_unstable_factorisation_is_loud(backend)
+
+
+def test_ensemble_equals_single_members(backend):
+    pc.check_ensemble_equals_single_members(backend, N=300, m1=8, m_upper=3)

@@ -216,3 +216,8 @@ def test_simulation_stays_resident():
 
 def test_unstable_factorisation_is_loud():
     pc.check_unstable_factorisation_is_loud(HIP)
+
+
+def test_ensemble_equals_single_members():
+    pc.check_ensemble_equals_single_members(HIP, N=30000)
+    pc.check_ensemble_equals_single_members(HIP, N=3000, nsys=2, m1=8, m_upper=3)

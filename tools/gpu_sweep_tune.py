@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 if len(sys.argv) > 1 and sys.argv[1] == 'one':
     import numpy as np
     from triflow_amd.model import Model
-    from oracle import corpus
+    from triflow_amd import workloads as corpus
     cfg = int(os.environ.get('CFG', '3'))
     name, fd, pars, dt, _ = corpus.config_inputs(cfg)
     m = Model(*corpus.model_args(name))
