@@ -17,9 +17,9 @@ Host control flow only; same constructor and behaviour as the reference's
 * a ``RuntimeError`` raised by the scheme sets ``status = 'failed'`` and is
   re-raised (``simulation.py:259-261``).
 
-The persistence container and the displays of the reference are I/O plugins
-outside the hot path; ``stream`` is a minimal in-process publisher so that
-user callbacks can still subscribe to the emitted simulation states.
+The displays of the reference are outside the hot path; ``stream`` is a minimal
+in-process publisher (user callbacks, the persistence container of
+``container.py``) for the emitted simulation states.
 """
 
 import datetime
@@ -186,11 +186,15 @@ class Simulation:
             total=datetime.timedelta(seconds=self._total_running), pars=pars,
             hook=hook_source, model=self.model)
 
-    def attach_container(self, *args, **kwargs):
-        raise NotImplementedError(
-            "the netCDF persistence container of the reference "
-            "(triflow/plugins/container.py) is an I/O plugin outside the hot path; "
-            "subscribe a callback with simulation.stream.sink(...) instead")
+    def attach_container(self, path=None, save="all", mode="w", nbuffer=50, force=False):
+        """Keep the emitted states (reference simulation.py:352-381): in memory, and under
+        ``path/<id>`` when a path is given.  See ``triflow_amd/container.py``."""
+        from .container import TriflowContainer
+        self._container = TriflowContainer("%s/%s" % (path, self.id) if path else None,
+                                           save=save, mode=mode, metadata=self.parameters,
+                                           force=force, nbuffer=nbuffer)
+        self._container.connect(self.stream)
+        return self._container
 
     @property
     def post_processes(self):
