@@ -67,6 +67,9 @@ typedef struct tf_solver_opts {
 
 const char* tf_last_error(void);
 int tf_runtime_info(int32_t* is_device_build, int32_t* device_count);
+/* current HIP device of the calling thread: code objects are loaded, and solvers
+ * created with device = -1 live, on it */
+int tf_set_device(int32_t ordinal);
 
 /* code object = gfx950 .hsaco image built from the generated per-model source */
 int tf_model_create(const tf_model_spec* spec, const void* code_object, size_t code_size,

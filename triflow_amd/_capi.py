@@ -31,6 +31,7 @@ class SolverOpts(C.Structure):
 SIGNATURES = {
     "tf_last_error": (C.c_char_p, []),
     "tf_runtime_info": (C.c_int, [c_int32_p, c_int32_p]),
+    "tf_set_device": (C.c_int, [C.c_int32]),
     "tf_model_create": (C.c_int, [C.POINTER(ModelSpec), C.c_void_p, C.c_size_t,
                                   C.POINTER(C.c_void_p)]),
     "tf_model_destroy": (None, [C.c_void_p]),
@@ -110,6 +111,9 @@ class Library:
         dev, cnt = C.c_int32(0), C.c_int32(0)
         self.call("tf_runtime_info", C.byref(dev), C.byref(cnt))
         return bool(dev.value), cnt.value
+
+    def set_device(self, ordinal):
+        self.call("tf_set_device", int(ordinal))
 
     def kernel_names(self):
         return [self.dll.tf_kernel_name(k).decode() for k in range(self.dll.tf_kernel_count())]

@@ -160,13 +160,15 @@ class HipBackend:
                 HipBackend._lib = Library(LIB_PATH)
             return HipBackend._lib
 
-    def load(self, model, parvec_mask):
+    def load(self, model, parvec_mask, device=-1):
         hsaco, spec = build_code_object(model, parvec_mask)
         lib = self.library()
         is_dev, ndev = lib.runtime_info()
         if ndev < 1:
             raise RuntimeError("no HIP device visible: the triflow_amd compute path needs "
                                "an MI355X (gfx950); there is no CPU fallback")
+        if device >= 0:
+            lib.set_device(device)          # the code object belongs to this GPU
         with open(hsaco, "rb") as f:
             code = f.read()
         return DeviceModel(lib, spec, code)
@@ -231,15 +233,19 @@ class CompiledModel:
         codegen.lower_model(model)
 
     # ---- code objects / solvers ------------------------------------------------
-    def device_model(self, parvec_mask=0):
-        if parvec_mask not in self._device_models:
-            self._device_models[parvec_mask] = self.backend.load(self.model, parvec_mask)
-        return self._device_models[parvec_mask]
+    def device_model(self, parvec_mask=0, device=-1):
+        key = (parvec_mask, device)
+        if key not in self._device_models:
+            if device >= 0:
+                self._device_models[key] = self.backend.load(self.model, parvec_mask, device)
+            else:
+                self._device_models[key] = self.backend.load(self.model, parvec_mask)
+        return self._device_models[key]
 
     def solver(self, N, periodic, nsys=1, parvec_mask=0, **opts):
         key = (int(N), bool(periodic), int(nsys), int(parvec_mask), tuple(sorted(opts.items())))
         if key not in self._solvers:
-            dm = self.device_model(parvec_mask)
+            dm = self.device_model(parvec_mask, int(opts.get("device", -1)))
             self._solvers[key] = DeviceSolver(dm, N, nsys=nsys, periodic=periodic, **opts)
         return self._solvers[key]
 

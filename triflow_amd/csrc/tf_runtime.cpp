@@ -447,6 +447,12 @@ int tf_runtime_info(int32_t* is_device_build, int32_t* device_count) {
     TF_API_END
 }
 
+int tf_set_device(int32_t ordinal) {
+    TF_API_BEGIN
+    tfb::set_device(ordinal);
+    TF_API_END
+}
+
 int tf_kernel_count(void) { return TFK_COUNT; }
 const char* tf_kernel_name(int32_t kernel) {
     static const char* names[TFK_COUNT] = TF_KERNEL_NAMES;
