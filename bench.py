@@ -60,17 +60,20 @@ def build_problem(cfg, N, table):
     return name, fd["x"], fields, pars, dt, scheme
 
 
-def cpu_baseline(cfg, N, scheme_name):
+def cpu_baseline(cfg, N, scheme_name, fair=False):
     """The reference's algorithm (oracle = NumPy/SciPy port of the numpy-compiler
-    path + SuperLU) on this box's host cores: one full-size step, single thread."""
+    path + SuperLU) on this box's host cores, full size, single thread.  ``fair``:
+    the same arithmetic without the reference's per-row ``np.stack`` interleave
+    (compilers.py:288), so that the comparison is not inflated by that pathology."""
     from oracle import numpy_path as ora          # the checker, timed as the CPU baseline
     from triflow_amd import Model, workloads
     name, fd, pars, dt, _ = workloads.config_inputs(cfg, N)
-    model = Model(*workloads.model_args(name), compiler=ora.numpy_compiler)
+    model = Model(*workloads.model_args(name),
+                  compiler=ora.fair_numpy_compiler if fair else ora.numpy_compiler)
     scheme = {"ROS2": ora.ROS2, "RODASPR": lambda m: ora.RODASPR(m, time_stepping=False),
               "Theta": ora.Theta, "BDF2": ora.BDF2}[scheme_name](model)
     fields = model.fields_template(**fd)
-    nsteps, t = 3, 0.0
+    nsteps, t = (2 if fair else 3), 0.0
     t0 = time.perf_counter()
     for _ in range(nsteps):
         t, fields = scheme(t, fields, dt, pars)
@@ -217,6 +220,7 @@ def main():
             out["scheme_api_steps_per_s"] = scheme_api_rate(model, args.config, N, scheme, dt)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, N, scheme)
+            out["cpu_baseline_fair"] = cpu_baseline(args.config, N, scheme, fair=True)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
