@@ -502,6 +502,9 @@ template <int B, int MP> struct TfTips {
 struct TfRowsL1 {
     static constexpr int B = TF_NVAR;
     static constexpr int MP = TF_MP;
+    // scalar equations: partial pivoting over the band inside the chunk interior
+    // (rows are exchanged, so U widens to 2*MP like LAPACK's gbtrf)
+    static constexpr bool PIVOT = TF_NVAR == 1;
     const TfLevelArgs& a;
     int pg, e, p, len, start;
     TF_DEVICE_M TfRowsL1(const TfLevelArgs& a_, int pg_) : a(a_), pg(pg_) {
@@ -563,6 +566,7 @@ template <int BB>
 struct TfRowsBT {
     static constexpr int B = BB;
     static constexpr int MP = 1;
+    static constexpr bool PIVOT = false;
     const TfLevelArgs& a;
     int pg, e, p, len, start;
     TF_DEVICE_M TfRowsBT(const TfLevelArgs& a_, int pg_) : a(a_), pg(pg_) {
@@ -595,6 +599,9 @@ struct TfRowsBT {
 template <class Rows, int DIR, bool SPIKE, bool STORE_U, bool STORE_Y>
 TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
     constexpr int B = Rows::B, MP = Rows::MP, W = 2 * MP + 1;
+    constexpr bool PIV = Rows::PIVOT;             // row exchanges inside the window (B == 1)
+    constexpr int UW = PIV ? 2 * MP : MP;         // blocks right of the pivot kept in U
+    static_assert(!PIV || B == 1, "row exchanges are written for scalar blocks");
     typedef TfTips<B, MP> Tip;
     const TfLayout& L = a.L;
     if (pg >= L.Ptot) return;
@@ -608,7 +615,7 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
     double y[MP + 1][B];
     double Es[SPIKE ? MP + 1 : 1][SPIKE ? MP : 1][B][B];   // columns: separator behind, local order
     // normalised rows of the last MP pivots (tips)
-    double Uh[MP][MP][B][B], yh[MP][B];
+    double Uh[MP][UW][B][B], yh[MP][B];
     double Eh[SPIKE ? MP : 1][SPIKE ? MP : 1][B][B];
     bool ok = true;
 
@@ -655,24 +662,46 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
         constexpr int HIST = decltype(hist_tag)::value;
         // normalise the pivot row first, fetch the incoming row afterwards: the
         // B x B temporaries of the inverse and the new row are never live together
-        double Un[MP][B][B], yn[B];
+        double Un[UW][B][B], yn[B];
         double En[SPIKE ? MP : 1][B][B];
+        if (PIV) {
+            // every row with an entry in column j is a candidate: bring in row
+            // j+MP first, then move the largest |entry| to slot 0
+            fetch(MP, j + MP);
+#pragma unroll
+            for (int q = 1; q <= MP; ++q) {
+                const bool sw = tf_abs(R[q][0][0][0]) > tf_abs(R[0][0][0][0]);
+#pragma unroll
+                for (int c = 0; c < W; ++c) {
+                    const double u = R[0][c][0][0], v = R[q][c][0][0];
+                    R[0][c][0][0] = sw ? v : u; R[q][c][0][0] = sw ? u : v;
+                }
+                { const double u = y[0][0], v = y[q][0]; y[0][0] = sw ? v : u; y[q][0] = sw ? u : v; }
+                if (SPIKE) {
+#pragma unroll
+                    for (int t = 0; t < MP; ++t) {
+                        const double u = Es[0][SPIKE ? t : 0][0][0], v = Es[SPIKE ? q : 0][SPIKE ? t : 0][0][0];
+                        Es[0][SPIKE ? t : 0][0][0] = sw ? v : u; Es[SPIKE ? q : 0][SPIKE ? t : 0][0][0] = sw ? u : v;
+                    }
+                }
+            }
+        }
         {
             double Dinv[B][B];
             ok = tf_blk_inverse<B>(R[0][0], Dinv) && ok;
 #pragma unroll
-            for (int c = 1; c <= MP; ++c) tf_mm<B>(Un[c - 1], Dinv, R[0][c]);
+            for (int c = 1; c <= UW; ++c) tf_mm<B>(Un[c - 1], Dinv, R[0][c]);
             tf_mv<B>(yn, Dinv, y[0]);
             if (SPIKE) {
 #pragma unroll
                 for (int t = 0; t < MP; ++t) tf_mm<B>(En[t], Dinv, Es[0][t]);
             }
         }
-        fetch(MP, j + MP);
+        if (!PIV) fetch(MP, j + MP);
 #pragma unroll
         for (int q = 1; q <= MP; ++q) {
 #pragma unroll
-            for (int c = 1; c <= MP; ++c) tf_mm_sub<B>(R[q][c], R[q][0], Un[c - 1]);
+            for (int c = 1; c <= UW; ++c) tf_mm_sub<B>(R[q][c], R[q][0], Un[c - 1]);
             tf_mv_sub<B>(y[q], R[q][0], yn);
             if (SPIKE) {
 #pragma unroll
@@ -683,13 +712,14 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
             const int64_t s = tf_idx(L, pg, node(j));
             if (STORE_U) {
 #pragma unroll
-                for (int c = 0; c < MP; ++c)
+                for (int c = 0; c < UW; ++c)
 #pragma unroll
                     for (int r = 0; r < B; ++r)
 #pragma unroll
                         for (int k = 0; k < B; ++k) {
                             a.Ut[(int64_t)((c * B + r) * B + k) * L.plane + s] = Un[c][r][k];
-                            if (SPIKE) a.Et[(int64_t)((c * B + r) * B + k) * L.plane + s] = En[SPIKE ? c : 0][r][k];
+                            if (SPIKE && c < MP)
+                                a.Et[(int64_t)((c * B + r) * B + k) * L.plane + s] = En[SPIKE && c < MP ? c : 0][r][k];
                         }
             }
             if (STORE_Y) {
@@ -700,7 +730,7 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
         if (HIST >= 0) {
             constexpr int H = HIST >= 0 ? HIST : 0;
 #pragma unroll
-            for (int c = 0; c < MP; ++c) tf_blk_copy<B>(Uh[H][c], Un[c]);
+            for (int c = 0; c < UW; ++c) tf_blk_copy<B>(Uh[H][c], Un[c]);
 #pragma unroll
             for (int r = 0; r < B; ++r) yh[H][r] = yn[r];
             if (SPIKE) {
@@ -744,9 +774,12 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
             }
         }
 #pragma unroll
-        for (int c = 1; c <= MP; ++c) {
+        for (int c = 1; c <= UW; ++c) {
             const int kk = k + c;
-            if (kk < MP) {
+            if (kk >= 2 * MP) {
+                // beyond the separator ahead: no interior row reaches there, the
+                // (exchanged) pivot row holds an exact zero
+            } else if (kk < MP) {
                 tf_mv_sub<B>(yb[k], Uh[k][c - 1], yb[kk]);
                 if (SPIKE) {
 #pragma unroll
@@ -1024,13 +1057,18 @@ TF_DEVICE void tfk_asm_body(const TfLevelArgs& a, int pg) {
 template <class Rows>
 TF_DEVICE void tfk_backsub_body(const TfLevelArgs& a, int pg) {
     constexpr int B = Rows::B, MP = Rows::MP;
+    constexpr int UW = Rows::PIVOT ? 2 * MP : MP;  // see tfk_chunk_body
     const TfLayout& L = a.L;
     if (pg >= L.Ptot) return;
     const int e = pg / L.P, p = pg - e * L.P;
     const int len = tf_len(L, p), mI = len - MP;
     const bool has_above = L.periodic || p > 0;
     const int pa = p > 0 ? p - 1 : L.P - 1;
-    double sa[MP][B], xn[MP][B];
+    double sa[MP][B], xn[UW][B];
+#pragma unroll
+    for (int t = MP; t < UW; ++t)                  // beyond the separator: coefficient is an exact zero
+#pragma unroll
+        for (int r = 0; r < B; ++r) xn[t][r] = 0.0;
     {
         int p2, i2;
         tf_locate(a.Lnext, p, p2, i2);
@@ -1054,19 +1092,19 @@ TF_DEVICE void tfk_backsub_body(const TfLevelArgs& a, int pg) {
     }
     // the factors of node j-1 are requested before node j is processed, so one
     // HBM latency is paid per chunk, not per node
-    struct Node { double y[B]; double U[MP][B][B]; double E[MP][B][B]; };
+    struct Node { double y[B]; double U[UW][B][B]; double E[MP][B][B]; };
     auto load = [&](int j, Node& n) {
         const int64_t s = tf_idx(L, pg, j);
 #pragma unroll
         for (int r = 0; r < B; ++r) n.y[r] = a.yt[(int64_t)r * L.plane + s];
 #pragma unroll
-        for (int c = 0; c < MP; ++c)
+        for (int c = 0; c < UW; ++c)
 #pragma unroll
             for (int r = 0; r < B; ++r)
 #pragma unroll
                 for (int k = 0; k < B; ++k) {
                     n.U[c][r][k] = a.Ut[(int64_t)((c * B + r) * B + k) * L.plane + s];
-                    n.E[c][r][k] = a.Et[(int64_t)((c * B + r) * B + k) * L.plane + s];
+                    if (c < MP) n.E[c < MP ? c : 0][r][k] = a.Et[(int64_t)((c * B + r) * B + k) * L.plane + s];
                 }
     };
     Node cur, nxt;
@@ -1078,12 +1116,11 @@ TF_DEVICE void tfk_backsub_body(const TfLevelArgs& a, int pg) {
 #pragma unroll
         for (int r = 0; r < B; ++r) x[r] = cur.y[r];
 #pragma unroll
-        for (int c = 0; c < MP; ++c) {
-            tf_mv_sub<B>(x, cur.U[c], xn[c]);
-            tf_mv_sub<B>(x, cur.E[c], sa[c]);
-        }
+        for (int c = 0; c < UW; ++c) tf_mv_sub<B>(x, cur.U[c], xn[c]);
 #pragma unroll
-        for (int c = MP - 1; c > 0; --c)
+        for (int c = 0; c < MP; ++c) tf_mv_sub<B>(x, cur.E[c], sa[c]);
+#pragma unroll
+        for (int c = UW - 1; c > 0; --c)
 #pragma unroll
             for (int r = 0; r < B; ++r) xn[c][r] = xn[c - 1][r];
 #pragma unroll

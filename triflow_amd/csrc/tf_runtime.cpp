@@ -541,7 +541,9 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
         Level& lv = *s->levels[l];
         const int B = lv.B, MP = lv.MP;
         const int64_t pl = lv.L.plane;
-        lv.Ut.alloc((size_t)MP * B * B * pl, tot);
+        // level 1 of a scalar model exchanges rows inside the band: U is 2*MP wide
+        const int UW = (l == 0 && B == 1) ? 2 * MP : MP;
+        lv.Ut.alloc((size_t)UW * B * B * pl, tot);
         lv.Et.alloc((size_t)MP * B * B * pl, tot);
         lv.yt.alloc((size_t)B * pl, tot);
         const size_t tipsz = (size_t)(MP * B + 2 * MP * MP * B * B) * lv.L.Ptot;
