@@ -34,6 +34,13 @@ MODELS = {
     "nonlin": ("k * dxxU + exp(-U**2) - sqrt(1 + U**2) + U**3", "U", "k", None),
     "M3_film": BENCH_MODELS["M3_film"],
     "M5_stiff": BENCH_MODELS["M5_stiff"],
+    # wide blocks: 4 variables with 5-point stencils (b = 8), 6 variables (b = 6)
+    "wide4": (["-dxxxxA - dxxA + B*dxA", "k*dxxB - A*dxxxC", "k*dxxC + dxD*A",
+               "k*dxxD - dxxxxD + B"], ["A", "B", "C", "D"], "k", None),
+    "six": (["k*dxx%s + %s*dx%s" % (v, w, v) for v, w in zip("ABCDGH", "BCDGHA")],
+            list("ABCDGH"), "k", None),
+    # a bare ``E`` is SymPy's Euler number in the reference's sympify namespace
+    "euler_const": ("k * dxxU + E * U + pi * dxU", "U", "k", None),
 }
 
 DEFAULT_PARS = {
@@ -51,6 +58,7 @@ DEFAULT_PARS = {
     "nonlin": dict(k=.1),
     "M3_film": dict(c=1., eps=.5, We=.01, k=.05),
     "M5_stiff": dict(Dm=1e-4, k1=.04, k2=3e7, k3=1e4, k4=1., c=.1),
+    "wide4": dict(k=.3), "six": dict(k=.2), "euler_const": dict(k=.1),
 }
 
 

@@ -18,7 +18,7 @@ def backend():
 
 FJ_MODELS = ["M1_advdiff", "M2_diff", "heat_nopar", "bivar", "helper", "helper_d",
              "upwind1_const", "upwind2_par", "upwind3_par", "upwind2_state", "burgers", "kdv",
-             "kuramoto", "wave", "nonlin", "M3_film", "M5_stiff"]
+             "kuramoto", "wave", "nonlin", "M3_film", "M5_stiff", "wide4", "six", "euler_const"]
 
 
 @pytest.mark.parametrize("name", FJ_MODELS)
@@ -31,11 +31,12 @@ def test_FJ_ragged_chunks(name, N, backend):
     pc.check_FJ_bitexact_large(name, backend, N)
 
 
-@pytest.mark.parametrize("name", ["M2_diff", "M3_film", "M5_stiff", "kuramoto"])
+@pytest.mark.parametrize("name", ["M2_diff", "M3_film", "M5_stiff", "kuramoto", "wide4", "six"])
 def test_linear_solve(name, backend):
     plans = [dict(m1=4, m_upper=2), dict(m1=7, m_upper=3), dict(m1=32, m_upper=8),
              dict(m1=10 ** 6), dict(m1=4, m_upper=2, tail_chunks=16)]
-    pc.check_linear_solve(name, backend, 203, plans, tol=1e-9)
+    # wide4: fourth derivatives at dx = 5e-3, cond(A) ~ 1e9 for both solvers
+    pc.check_linear_solve(name, backend, 203, plans, tol=1e-7 if name == "wide4" else 1e-9)
 
 
 @pytest.mark.parametrize("case", [c for c in pc.STEP_CASES if c[0] in

@@ -36,7 +36,7 @@ def test_FJ_bitexact_ragged(name, N):
 
 
 @pytest.mark.parametrize("name", ["M2_diff", "M1_advdiff", "M3_film", "M5_stiff", "kuramoto",
-                                  "kdv", "wave", "upwind2_par"])
+                                  "kdv", "wave", "upwind2_par", "wide4", "six"])
 def test_linear_solve_small(name):
     plans = [dict(m1=4, m_upper=2), dict(m1=7, m_upper=3), dict(m1=32, m_upper=8),
              dict(m1=10 ** 6), dict()]
@@ -45,12 +45,16 @@ def test_linear_solve_small(name):
         # across nodes, so very short chunks lose accuracy ("solver
         # limits"); the default plan plus automatic refinement is what is supported
         plans = [dict(m1=32, m_upper=8), dict()]
-    pc.check_linear_solve(name, HIP, 203, plans, tol=1e-9)
+    # wide4: fourth derivatives at dx = 5e-3, cond(A) ~ 1e9 for both solvers; kdv: backward
+    # error 5e-11 (below the refinement trigger of 1e-10) times cond(A) ~ 1e2
+    tol = {"wide4": 1e-7, "kdv": 2e-8}.get(name, 1e-9)
+    pc.check_linear_solve(name, HIP, 203, plans, tol=tol)
 
 
-@pytest.mark.parametrize("name", ["M2_diff", "M3_film", "M5_stiff"])
+@pytest.mark.parametrize("name", ["M2_diff", "M3_film", "M5_stiff", "wide4", "six"])
 def test_linear_solve_medium(name):
-    pc.check_linear_solve(name, HIP, 20011, [dict(), dict(m1=16, m_upper=4)], tol=1e-8)
+    pc.check_linear_solve(name, HIP, 20011, [dict(), dict(m1=16, m_upper=4)],
+                          tol=1e-6 if name == "wide4" else 1e-8)
 
 
 @pytest.mark.parametrize("case", STEP_CASES, ids=lambda c: c[0])

@@ -69,7 +69,7 @@ class _CEmitter(ast.NodeVisitor):
         if isinstance(node, ast.Constant):
             return True
         if isinstance(node, ast.Name):
-            return node.id in self.uniform_names or node.id in ("pi", "E")
+            return node.id in self.uniform_names or node.id in ("pi", "E", "e")
         if isinstance(node, ast.UnaryOp):
             return self.is_uniform(node.operand)
         if isinstance(node, ast.BinOp):
@@ -88,7 +88,7 @@ class _CEmitter(ast.NodeVisitor):
             return self.names[node.id]
         if node.id == "pi":
             return _dbl(np.pi)
-        if node.id == "E":
+        if node.id in ("E", "e"):           # SymPy's Euler number, printed as numpy.e
             return _dbl(np.e)
         raise UnsupportedExpression("unknown symbol %r in stencil expression" % node.id)
 
@@ -309,7 +309,7 @@ def lower_model(model, parvec_mask=0, seg=8, sweep_block=64):
 _HOST_NS = {name: getattr(np, name) for name in
             ("sqrt", "exp", "log", "sin", "cos", "tan", "tanh", "sinh", "cosh", "arctan", "arcsin",
              "arccos", "log10", "log2", "cbrt", "expm1", "log1p", "maximum", "minimum", "pi")}
-_HOST_NS["E"] = np.e
+_HOST_NS["E"] = _HOST_NS["e"] = np.e
 
 
 def eval_host_constants(spec, dx, par_values):
