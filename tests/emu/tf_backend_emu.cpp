@@ -29,6 +29,7 @@ struct Event { int dummy; };
 
 bool is_device_build() { return false; }
 int coop_group(int) { return 1; }
+bool cyclic_reduction(int) { return false; }   // HIP only (wave-cooperative)
 int device_count() { return 0; }
 void set_device(int) {}
 void* dev_alloc(size_t bytes) { void* p = std::calloc(bytes ? bytes : 8, 1); if (!p) throw std::bad_alloc(); return p; }

@@ -18,6 +18,8 @@ struct Event;
 bool is_device_build();
 // lanes that share one chunk in the reduced-level kernels of block size b
 int coop_group(int b);
+// reduced levels of block size b run the cyclic-reduction kernels (tfk_cr_*)
+bool cyclic_reduction(int b);
 int device_count();
 void set_device(int ordinal);                 // throws std::runtime_error
 

@@ -25,6 +25,13 @@ struct Event { hipEvent_t e; };
 bool is_device_build() { return true; }
 int coop_group(int b) { return b <= 2 ? 1 : (b <= 8 ? 8 : (b <= 16 ? 16 : 1)); }   // TfCoop<b>::G
 
+bool cyclic_reduction(int b) {
+    // TRIFLOW_REDUCED=walk selects the chunk walks of tfk_bt_* instead (A/B comparisons)
+    const char* mode = getenv("TRIFLOW_REDUCED");
+    if (mode && std::string(mode) == "walk") return false;
+    return b >= 3 && b <= 8;
+}
+
 int device_count() {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

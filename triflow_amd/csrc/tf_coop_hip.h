@@ -395,3 +395,415 @@ __device__ __forceinline__ void tfk_bt_asm_coop(const TfLevelArgs& a) {
         }
     }
 }
+
+// ===========================================================================
+// Cyclic reduction inside the chunks of the reduced levels (3 <= b <= 8)
+// ===========================================================================
+// The walks above are latency-bound: a chunk of m nodes costs m-1 dependent
+// block inversions.  Here ONE wavefront owns a chunk of up to 16 nodes and
+// eliminates its interior in nested-dissection order: in round r every second
+// remaining interior node goes at once (8 lanes per node, 8 nodes per round),
+// so 15 interior nodes cost 4 dependent inversions instead of 15, and the
+// Schur complement on the two separators that bound the chunk comes out of the
+// last round -- no separate assemble kernel.  Levels shrink 16x per launch.
+//
+// Chain positions of chunk p: 0 = separator above (last node of chunk p-1),
+// 1..mI = interior nodes, pe = mI+1 = own separator; position pos >= 1 is node
+// start+pos-1.  Row pos keeps (L, D, U) = coupling to its current left
+// neighbour, itself, its current right neighbour.  Round with stride s
+// eliminates k = s*(odd) <= mI; its neighbours are k-s and (k+s <= mI ? k+s : pe):
+//   E_k = D_k^-1 L_k,  F_k = D_k^-1 U_k,  z_k = D_k^-1 y_k
+//   left  a:  D_a -= U_a E_k,  U_a' = -U_a F_k,  y_a -= U_a z_k
+//   right b:  D_b -= L_b F_k,  L_b' = -L_b E_k,  y_b -= L_b z_k
+// Stored per eliminated node (a.crf): D^-1, E, F, the U_a and L_b used above;
+// a.zt holds z.  Buffers of these levels are records per node in natural order
+// (TfLevelArgs).  What is left of rows 0 and pe is this chunk's share of the next
+// level's rows: node p gets (L, D) from its own chunk and (U, second part of D)
+// from chunk p+1.
+template <int BB> struct TfCr {
+    static constexpr int MAXLEN = TF_CR_MAXLEN;  // nodes per chunk
+    static constexpr int NPOS = MAXLEN + 1;
+    static constexpr int G = 8, NGRP = 8;
+};
+
+template <int BB>
+struct TfCrChunk {
+    int pg, e, p, len, start, mI, pe, gprev, pprev;
+    bool has_prev;
+    int64_t nbase;                                // first node record of system e
+    __device__ __forceinline__ TfCrChunk(const TfLayout& L) {
+        pg = blockIdx.x;
+        e = pg / L.P; p = pg - e * L.P;
+        len = tf_len(L, p); start = tf_start(L, p);
+        mI = len - 1; pe = len;
+        has_prev = L.periodic || p > 0;
+        gprev = start > 0 ? start - 1 : L.N - 1;
+        pprev = p > 0 ? p - 1 : L.P - 1;
+        nbase = (int64_t)e * L.N;
+    }
+    __device__ __forceinline__ int node(int pos) const { return start + pos - 1; }   // pos >= 1
+};
+
+// Gauss-Jordan inverse of a b x b block shared by the 8 lanes of a group: lane g
+// enters with row g of the block in S and leaves with row `myk` (returned) of the
+// inverse in INV.  Rows are never moved: the lane with the largest |S[.][k]| among
+// the lanes not used yet serves pivot k and publishes its row through `xch`
+// ([2][G][2b+1] doubles of this group, double buffered: one LDS round per pivot).
+template <int BB, int G>
+__device__ __forceinline__ int tf_gj_coop(double (&S)[BB], double (&INV)[BB], bool on, int g,
+                                          double* xch, bool& ok) {
+    constexpr int RS = 2 * BB + 1;
+    int myk = -1;
+#pragma unroll
+    for (int c = 0; c < BB; ++c) INV[c] = c == g ? 1.0 : 0.0;
+    auto publish = [&](int kk) {
+        double* dst = xch + ((kk & 1) * G + g) * RS;
+#pragma unroll
+        for (int c = 0; c < BB; ++c) { dst[c] = S[c]; dst[BB + c] = INV[c]; }
+        dst[2 * BB] = (on && myk < 0) ? tf_abs(S[kk]) : -1.0;
+    };
+    publish(0);
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BB; ++kk) {
+        const double* buf = xch + (kk & 1) * G * RS;
+        int piv = 0;
+        double best = -2.0;
+#pragma unroll
+        for (int r = 0; r < BB; ++r) {
+            const double v = buf[r * RS + 2 * BB];
+            if (v > best) { best = v; piv = r; }
+        }
+        const double* prow = buf + piv * RS;
+        const double pv = prow[kk];
+        if (on) ok = ok && (pv != 0.0) && tf_finite(pv);
+        const double rp = 1.0 / pv;
+        const bool mine = g == piv;
+        if (mine) myk = kk;
+        // every other row: S -= (S[k]/pv) * pivot row; the pivot row itself is scaled
+        const double f2 = mine ? 0.0 : -S[kk] * rp;
+#pragma unroll
+        for (int c = 0; c < BB; ++c) {
+            S[c] = tf_fma(f2, prow[c], S[c]);
+            INV[c] = tf_fma(f2, prow[BB + c], INV[c]);
+        }
+        if (mine) {
+#pragma unroll
+            for (int c = 0; c < BB; ++c) { S[c] *= rp; INV[c] *= rp; }
+        }
+        if (kk + 1 < BB) publish(kk + 1);
+        __syncthreads();
+    }
+    return myk;
+}
+
+template <int BB>
+__device__ __forceinline__ void tfk_cr_factor_coop(const TfLevelArgs& a) {
+    typedef TfCr<BB> C;
+    constexpr int G = C::G, NGRP = C::NGRP, NPOS = C::NPOS, B2 = BB * BB, REC = 4 * B2;
+    const TfLayout& L = a.L;
+    const TfCrChunk<BB> ch(L);
+    const int tid = threadIdx.x, grp = tid / G, g = tid % G;
+    const bool row_on = g < BB;
+    const int gq = row_on ? g : 0;
+    const int mI = ch.mI, pe = ch.pe, len = ch.len;
+    const bool with_rhs = a.cr_rhs != 0;
+
+    // rows of the chain as records [pos][L, D, U, second part of D][b][b]
+    __shared__ __attribute__((aligned(16))) double sRec[NPOS * REC];
+    __shared__ double sYr[NPOS * 2 * BB], sY[NPOS][BB], sZ[NPOS][BB];
+    __shared__ double sX[NGRP * 2 * G * (2 * BB + 1)];
+    auto rL = [&](int pos) { return sRec + pos * REC; };
+    auto rD = [&](int pos) { return sRec + pos * REC + B2; };
+    auto rU = [&](int pos) { return sRec + pos * REC + 2 * B2; };
+
+    // ---- load: the records of a chunk are contiguous (natural node order)
+    {
+        const double2* src = (const double2*)(a.Ablk + (ch.nbase + ch.start) * REC);
+        double2* dst = (double2*)(sRec + REC);
+        const int n2 = len * REC / 2;
+#pragma unroll
+        for (int it = 0; it < (C::MAXLEN * REC / 2 + 63) / 64; ++it) {
+            const int i = it * 64 + tid;
+            if (i < n2) dst[i] = src[i];
+        }
+        const double* prev = a.Ablk + (ch.nbase + ch.gprev) * REC;
+        for (int i = tid; i < REC; i += 64)
+            sRec[i] = (ch.has_prev && i >= 2 * B2 && i < 3 * B2) ? prev[i] : 0.0;
+        if (with_rhs) {
+            const double* ys = a.rhs + (ch.nbase + ch.start) * 2 * BB;
+            for (int i = tid; i < len * 2 * BB; i += 64) sYr[2 * BB + i] = ys[i];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < len * B2; i += 64) {       // D = both parts
+        const int pos = 1 + i / B2, rc = i - (pos - 1) * B2;
+        sRec[pos * REC + B2 + rc] += sRec[pos * REC + 3 * B2 + rc];
+    }
+    for (int i = tid; i < (len + 1) * BB; i += 64) {
+        const int pos = i / BB, r = i - pos * BB;
+        sY[pos][r] = (with_rhs && pos > 0) ? sYr[pos * 2 * BB + r] + sYr[pos * 2 * BB + BB + r] : 0.0;
+    }
+    if (!L.periodic) {                               // no neighbour beyond the ends of a system
+        if (ch.start == 0) for (int i = tid; i < B2; i += 64) rL(1)[i] = 0.0;
+        if (ch.start + len == L.N) for (int i = tid; i < B2; i += 64) rU(pe)[i] = 0.0;
+    }
+    __syncthreads();
+
+    bool ok = true;
+    for (int s = 1; s <= mI; s <<= 1) {
+        // ---- phase A: invert the diagonal blocks of the nodes that go this round
+        const int nA = (mI / s + 1) / 2;             // <= 8: one per group
+        {
+            const bool on = grp < nA && row_on;
+            const int k = grp < nA ? s * (2 * grp + 1) : 1;
+            double S[BB], INV[BB];
+#pragma unroll
+            for (int c = 0; c < BB; ++c) S[c] = rD(k)[gq * BB + c];
+            const int myk = tf_gj_coop<BB, G>(S, INV, on, g, sX + grp * 2 * G * (2 * BB + 1), ok);
+            // this lane holds row myk of D_k^-1
+            double Er[BB], Fr[BB], z = 0.0;
+#pragma unroll
+            for (int c = 0; c < BB; ++c) { Er[c] = 0.0; Fr[c] = 0.0; }
+#pragma unroll
+            for (int m = 0; m < BB; ++m) {
+#pragma unroll
+                for (int c = 0; c < BB; ++c) {
+                    Er[c] = tf_fma(INV[m], rL(k)[m * BB + c], Er[c]);
+                    Fr[c] = tf_fma(INV[m], rU(k)[m * BB + c], Fr[c]);
+                }
+                z = tf_fma(INV[m], sY[k][m], z);
+            }
+            if (on) {
+                double* rec = a.crf + (ch.nbase + ch.node(k)) * 5 * B2;
+#pragma unroll
+                for (int c = 0; c < BB; ++c) {
+                    rec[0 * B2 + myk * BB + c] = INV[c];
+                    rec[1 * B2 + myk * BB + c] = Er[c];
+                    rec[2 * B2 + myk * BB + c] = Fr[c];
+                }
+                if (with_rhs) a.zt[(ch.nbase + ch.node(k)) * BB + myk] = z;
+            }
+            __syncthreads();                         // every lane has read L_k, U_k, y_k
+            if (on) {
+#pragma unroll
+                for (int c = 0; c < BB; ++c) { rL(k)[myk * BB + c] = Er[c]; rU(k)[myk * BB + c] = Fr[c]; }
+                sZ[k][myk] = z;
+            }
+        }
+        __syncthreads();
+        // ---- phase B: the neighbours take the update, one task per group.  Interior
+        //      a = 2s(t+1): its L side lost kL = a-s, its U side loses kR = a+s (if there).
+        //      Last task: the L side of the own separator (pe) and the U side of position 0.
+        const int nB = mI / (2 * s);                 // <= 7
+        if (row_on && grp <= nB) {
+            const bool ends = grp == nB;
+            const int aa = 2 * s * (grp + 1), nq = mI / s;
+            const int aL = ends ? pe : aa, aU = ends ? 0 : aa;
+            const bool vL = ends ? (nq & 1) != 0 : true;
+            const bool vR = ends ? true : aa + s <= mI;
+            const int kL = ends ? nq * s : aa - s, kR = ends ? s : aa + s;
+            const int kLs = vL ? kL : 1, kRs = vR ? kR : 1;
+            double Lr[BB], Ur[BB];
+#pragma unroll
+            for (int c = 0; c < BB; ++c) { Lr[c] = rL(aL)[g * BB + c]; Ur[c] = rU(aU)[g * BB + c]; }
+            if (vL) {
+                double* rec = a.crf + (ch.nbase + ch.node(kL)) * 5 * B2 + 4 * B2 + g * BB;
+#pragma unroll
+                for (int c = 0; c < BB; ++c) rec[c] = Lr[c];
+            }
+            if (vR) {
+                double* rec = a.crf + (ch.nbase + ch.node(kR)) * 5 * B2 + 3 * B2 + g * BB;
+#pragma unroll
+                for (int c = 0; c < BB; ++c) rec[c] = Ur[c];
+            }
+            double nl[BB], dl[BB], nu[BB], du[BB], yl = 0.0, yu = 0.0;
+#pragma unroll
+            for (int c = 0; c < BB; ++c) { nl[c] = 0.0; dl[c] = 0.0; nu[c] = 0.0; du[c] = 0.0; }
+#pragma unroll
+            for (int m = 0; m < BB; ++m) {
+#pragma unroll
+                for (int c = 0; c < BB; ++c) {
+                    nl[c] = tf_fma(-Lr[m], rL(kLs)[m * BB + c], nl[c]);      // -L E_kL
+                    dl[c] = tf_fma(-Lr[m], rU(kLs)[m * BB + c], dl[c]);      // -L F_kL
+                    nu[c] = tf_fma(-Ur[m], rU(kRs)[m * BB + c], nu[c]);      // -U F_kR
+                    du[c] = tf_fma(-Ur[m], rL(kRs)[m * BB + c], du[c]);      // -U E_kR
+                }
+                yl = tf_fma(-Lr[m], sZ[kLs][m], yl);
+                yu = tf_fma(-Ur[m], sZ[kRs][m], yu);
+            }
+            if (vL) {
+#pragma unroll
+                for (int c = 0; c < BB; ++c) { rL(aL)[g * BB + c] = nl[c]; rD(aL)[g * BB + c] += dl[c]; }
+                sY[aL][g] += yl;
+            }
+            if (vR) {
+#pragma unroll
+                for (int c = 0; c < BB; ++c) { rU(aU)[g * BB + c] = nu[c]; rD(aU)[g * BB + c] += du[c]; }
+                sY[aU][g] += yu;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- this chunk's share of the next level's rows
+    if (row_on && grp < 2) {
+        const int nn = grp == 0 ? ch.p : ch.pprev;
+        double* rec = a.Anext + ((int64_t)ch.e * a.Lnext.N + nn) * REC;
+        double* rr = a.rhsnext + ((int64_t)ch.e * a.Lnext.N + nn) * 2 * BB;
+        if (grp == 0) {
+#pragma unroll
+            for (int c = 0; c < BB; ++c) { rec[0 * B2 + g * BB + c] = rL(pe)[g * BB + c]; rec[1 * B2 + g * BB + c] = rD(pe)[g * BB + c]; }
+            if (with_rhs) rr[g] = sY[pe][g];
+        } else {
+#pragma unroll
+            for (int c = 0; c < BB; ++c) { rec[2 * B2 + g * BB + c] = rU(0)[g * BB + c]; rec[3 * B2 + g * BB + c] = rD(0)[g * BB + c]; }
+            if (with_rhs) rr[BB + g] = sY[0][g];
+        }
+    }
+    if (!ok) *a.status = 1;
+}
+
+// Rows of the stored reduction that a lane needs in round r are known up front
+// (one task per group and phase), so the solve kernels request all of them
+// before the first round: one memory latency per launch instead of one per round.
+template <int BB>
+__device__ __forceinline__ void tfk_cr_fwd_coop(const TfLevelArgs& a) {
+    typedef TfCr<BB> C;
+    constexpr int G = C::G, NPOS = C::NPOS, B2 = BB * BB, MAXR = 4;
+    static_assert(C::MAXLEN <= 16, "round count");
+    const TfLayout& L = a.L;
+    const TfCrChunk<BB> ch(L);
+    const int tid = threadIdx.x, grp = tid / G, g = tid % G;
+    const bool row_on = g < BB;
+    const int mI = ch.mI, pe = ch.pe, len = ch.len;
+    __shared__ double sYr[NPOS * 2 * BB], sY[NPOS][BB], sZ[NPOS][BB];
+
+    {
+        const double* ys = a.rhs + (ch.nbase + ch.start) * 2 * BB;
+        for (int i = tid; i < len * 2 * BB; i += 64) sYr[2 * BB + i] = ys[i];
+    }
+    double Di[MAXR][BB], Lb[MAXR][BB], Ua[MAXR][BB];
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+        const int s = 1 << r;
+        const int nA = (mI / s + 1) / 2, nB = mI / (2 * s), nq = mI / s;
+        const bool onA = s <= mI && grp < nA && row_on;
+        const bool onB = s <= mI && grp <= nB && row_on;
+        const bool ends = grp == nB;
+        const int aa = 2 * s * (grp + 1);
+        const bool vL = onB && (ends ? (nq & 1) != 0 : true);
+        const bool vR = onB && (ends ? true : aa + s <= mI);
+        const int k = s * (2 * grp + 1), kL = ends ? nq * s : aa - s, kR = ends ? s : aa + s;
+        const double* rk = a.crf + (ch.nbase + ch.node(onA ? k : 1)) * 5 * B2 + g * BB;
+        const double* rl = a.crf + (ch.nbase + ch.node(vL ? kL : 1)) * 5 * B2 + 4 * B2 + g * BB;
+        const double* rr = a.crf + (ch.nbase + ch.node(vR ? kR : 1)) * 5 * B2 + 3 * B2 + g * BB;
+#pragma unroll
+        for (int m = 0; m < BB; ++m) {
+            Di[r][m] = onA ? rk[m] : 0.0;
+            Lb[r][m] = vL ? rl[m] : 0.0;
+            Ua[r][m] = vR ? rr[m] : 0.0;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < (len + 1) * BB; i += 64) {
+        const int pos = i / BB, r = i - pos * BB;
+        sY[pos][r] = pos > 0 ? sYr[pos * 2 * BB + r] + sYr[pos * 2 * BB + BB + r] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+        const int s = 1 << r;
+        if (s <= mI) {
+            const int nA = (mI / s + 1) / 2, nB = mI / (2 * s), nq = mI / s;
+            if (grp < nA && row_on) {
+                const int k = s * (2 * grp + 1);
+                double z = 0.0;
+#pragma unroll
+                for (int m = 0; m < BB; ++m) z = tf_fma(Di[r][m], sY[k][m], z);
+                sZ[k][g] = z;
+                a.zt[(ch.nbase + ch.node(k)) * BB + g] = z;
+            }
+            __syncthreads();
+            if (grp <= nB && row_on) {
+                const bool ends = grp == nB;
+                const int aa = 2 * s * (grp + 1);
+                const int aL = ends ? pe : aa, aU = ends ? 0 : aa;
+                const bool vL = ends ? (nq & 1) != 0 : true;
+                const bool vR = ends ? true : aa + s <= mI;
+                const int kL = vL ? (ends ? nq * s : aa - s) : 1, kR = vR ? (ends ? s : aa + s) : 1;
+                double yl = 0.0, yu = 0.0;
+#pragma unroll
+                for (int m = 0; m < BB; ++m) {
+                    yl = tf_fma(-Lb[r][m], sZ[kL][m], yl);      // rows are zero where there is no update
+                    yu = tf_fma(-Ua[r][m], sZ[kR][m], yu);
+                }
+                if (vL) sY[aL][g] += yl;
+                if (vR) sY[aU][g] += yu;
+            }
+            __syncthreads();
+        }
+    }
+    if (row_on && grp < 2) {
+        const int nn = grp == 0 ? ch.p : ch.pprev;
+        double* rr = a.rhsnext + ((int64_t)ch.e * a.Lnext.N + nn) * 2 * BB;
+        if (grp == 0) rr[g] = sY[pe][g]; else rr[BB + g] = sY[0][g];
+    }
+}
+
+// back-substitution: the separators that bound the chunk are known
+template <int BB>
+__device__ __forceinline__ void tfk_cr_bwd_coop(const TfLevelArgs& a) {
+    typedef TfCr<BB> C;
+    constexpr int G = C::G, NPOS = C::NPOS, B2 = BB * BB, MAXR = 4;
+    const TfLayout& L = a.L;
+    const TfCrChunk<BB> ch(L);
+    const int tid = threadIdx.x, grp = tid / G, g = tid % G;
+    const bool row_on = g < BB;
+    const int mI = ch.mI, pe = ch.pe;
+    __shared__ double sX[NPOS][BB];
+
+    double Er[MAXR][BB], Fr[MAXR][BB], zk[MAXR];
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+        const int s = 1 << r;
+        const int nA = (mI / s + 1) / 2;
+        const bool on = s <= mI && grp < nA && row_on;
+        const int k = on ? s * (2 * grp + 1) : 1;
+        const double* rec = a.crf + (ch.nbase + ch.node(k)) * 5 * B2 + g * BB;
+#pragma unroll
+        for (int m = 0; m < BB; ++m) {
+            Er[r][m] = on ? rec[1 * B2 + m] : 0.0;
+            Fr[r][m] = on ? rec[2 * B2 + m] : 0.0;
+        }
+        zk[r] = on ? a.zt[(ch.nbase + ch.node(k)) * BB + g] : 0.0;
+    }
+    if (row_on && grp == 0) {
+        const double xs = a.xnext[((int64_t)ch.e * a.Lnext.N + ch.p) * BB + g];
+        sX[pe][g] = xs;
+        a.x[(ch.nbase + ch.node(pe)) * BB + g] = xs;
+    }
+    if (row_on && grp == 1)
+        sX[0][g] = ch.has_prev ? a.xnext[((int64_t)ch.e * a.Lnext.N + ch.pprev) * BB + g] : 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int r = MAXR - 1; r >= 0; --r) {
+        const int s = 1 << r;
+        if (s <= mI) {
+            const int nA = (mI / s + 1) / 2;
+            if (grp < nA && row_on) {
+                const int k = s * (2 * grp + 1);
+                const int kl = k - s, kr = k + s <= mI ? k + s : pe;
+                double xk = zk[r];
+#pragma unroll
+                for (int m = 0; m < BB; ++m) {
+                    xk = tf_fma(-Er[r][m], sX[kl][m], xk);
+                    xk = tf_fma(-Fr[r][m], sX[kr][m], xk);
+                }
+                sX[k][g] = xk;
+                a.x[(ch.nbase + ch.node(k)) * BB + g] = xk;
+            }
+            __syncthreads();
+        }
+    }
+}

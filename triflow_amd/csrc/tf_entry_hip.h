@@ -147,6 +147,17 @@ __global__ void __launch_bounds__(64) tfk_bt_backsub(TfLevelArgs a) {
 __global__ void __launch_bounds__(64) tfk_top_factor(TfTopArgs a) { tfk_top_body<TF_B2, true>(a, TF_GID); }
 __global__ void __launch_bounds__(64) tfk_top_solve(TfTopArgs a) { tfk_top_body<TF_B2, false>(a, TF_GID); }
 
+// ---- cyclic-reduction levels (tf_coop_hip.h): one wavefront per chunk, 3 <= b <= 8
+__global__ void __launch_bounds__(64) tfk_cr_factor(TfLevelArgs a) {
+    if constexpr (TF_B2 >= 3 && TF_B2 <= 8) tfk_cr_factor_coop<TF_B2>(a);
+}
+__global__ void __launch_bounds__(64) tfk_cr_fwd(TfLevelArgs a) {
+    if constexpr (TF_B2 >= 3 && TF_B2 <= 8) tfk_cr_fwd_coop<TF_B2>(a);
+}
+__global__ void __launch_bounds__(64) tfk_cr_bwd(TfLevelArgs a) {
+    if constexpr (TF_B2 >= 3 && TF_B2 <= 8) tfk_cr_bwd_coop<TF_B2>(a);
+}
+
 // one workgroup of 256 threads; phases separated by workgroup barriers (the data
 // handed from phase to phase stays on this CU: same L1, L2 write-through)
 __global__ void __launch_bounds__(256) tfk_tail(TfTailArgs a) {

@@ -68,6 +68,20 @@ TF_DEVICE void tf_locate(const TfLayout& L, int g, int& p, int& i) {
     else { int h = g - big; p = L.rem + h / L.mbase; i = h - (h / L.mbase) * L.mbase; }
 }
 
+// element addresses in the NEXT solver level, which is stored either as
+// partition-interleaved planes (s2 = tf_idx of the separator there) or, below
+// cyclic-reduction levels, as one record per node in natural order (TfLevelArgs)
+TF_DEVICE int64_t tf_next_A(const TfLevelArgs& a, int e, int p, int64_t s2, int blk, int rr, int cc, int bn) {
+    return a.next_aos ? (((int64_t)(e * a.Lnext.N + p) * 4 + blk) * bn + rr) * bn + cc
+                      : (int64_t)((blk * bn + rr) * bn + cc) * a.Lnext.plane + s2;
+}
+TF_DEVICE int64_t tf_next_rhs(const TfLevelArgs& a, int e, int p, int64_t s2, int k, int bn) {
+    return a.next_aos ? (int64_t)(e * a.Lnext.N + p) * 2 * bn + k : (int64_t)k * a.Lnext.plane + s2;
+}
+TF_DEVICE int64_t tf_next_x(const TfLevelArgs& a, int e, int p, int64_t s2, int k, int bn) {
+    return a.next_aos ? (int64_t)(e * a.Lnext.N + p) * bn + k : (int64_t)k * a.Lnext.plane + s2;
+}
+
 // ===========================================================================
 // 1. F / F+J stencil sweep                       (compilers.py:227-332)
 // ===========================================================================
@@ -1036,7 +1050,7 @@ TF_DEVICE void tfk_asm_body(const TfLevelArgs& a, int pg) {
             }
         }
 #pragma unroll
-        for (int r = 0; r < B; ++r) a.rhsnext[(int64_t)(t * B + r) * a.Lnext.plane + s2] = g[r];
+        for (int r = 0; r < B; ++r) a.rhsnext[tf_next_rhs(a, e, p, s2, t * B + r, BB)] = g[r];
         if (MATRIX) {
 #pragma unroll
             for (int t2 = 0; t2 < MP; ++t2)
@@ -1045,9 +1059,9 @@ TF_DEVICE void tfk_asm_body(const TfLevelArgs& a, int pg) {
 #pragma unroll
                     for (int c = 0; c < B; ++c) {
                         const int rr = t * B + r, cc = t2 * B + c;
-                        a.Anext[(int64_t)((0 * BB + rr) * BB + cc) * a.Lnext.plane + s2] = sub[t2][r][c];
-                        a.Anext[(int64_t)((1 * BB + rr) * BB + cc) * a.Lnext.plane + s2] = dia[t2][r][c];
-                        a.Anext[(int64_t)((2 * BB + rr) * BB + cc) * a.Lnext.plane + s2] = sup[t2][r][c];
+                        a.Anext[tf_next_A(a, e, p, s2, 0, rr, cc, BB)] = sub[t2][r][c];
+                        a.Anext[tf_next_A(a, e, p, s2, 1, rr, cc, BB)] = dia[t2][r][c];
+                        a.Anext[tf_next_A(a, e, p, s2, 2, rr, cc, BB)] = sup[t2][r][c];
                     }
         }
     }
@@ -1076,13 +1090,13 @@ TF_DEVICE void tfk_backsub_body(const TfLevelArgs& a, int pg) {
 #pragma unroll
         for (int t = 0; t < MP; ++t)
 #pragma unroll
-            for (int r = 0; r < B; ++r) xn[t][r] = a.xnext[(int64_t)(t * B + r) * a.Lnext.plane + s2];
+            for (int r = 0; r < B; ++r) xn[t][r] = a.xnext[tf_next_x(a, e, p, s2, t * B + r, MP * B)];
         tf_locate(a.Lnext, pa, p2, i2);
         const int64_t s2a = tf_idx(a.Lnext, e * a.Lnext.P + p2, i2);
 #pragma unroll
         for (int t = 0; t < MP; ++t)
 #pragma unroll
-            for (int r = 0; r < B; ++r) sa[t][r] = has_above ? a.xnext[(int64_t)(t * B + r) * a.Lnext.plane + s2a] : 0.0;
+            for (int r = 0; r < B; ++r) sa[t][r] = has_above ? a.xnext[tf_next_x(a, e, pa, s2a, t * B + r, MP * B)] : 0.0;
     }
 #pragma unroll
     for (int t = 0; t < MP; ++t) {
@@ -1133,15 +1147,20 @@ TF_DEVICE void tfk_backsub_body(const TfLevelArgs& a, int pg) {
 template <int BB, bool FACTOR>
 TF_DEVICE void tfk_top_body(const TfTopArgs& a, int e) {
     if (e >= a.nsys) return;
+    // aos: records per system written by a cyclic-reduction level (TfLevelArgs)
+    auto A = [&](int blk, int r, int c) {
+        return a.aos ? a.A[(((int64_t)e * 4 + blk) * BB + r) * BB + c]
+                     : a.A[(int64_t)((blk * BB + r) * BB + c) * a.nsys + e];
+    };
     if (FACTOR) {
         double D[BB][BB], Di[BB][BB];
 #pragma unroll
         for (int r = 0; r < BB; ++r)
 #pragma unroll
-            for (int c = 0; c < BB; ++c)
-                D[r][c] = a.A[(int64_t)((0 * BB + r) * BB + c) * a.nsys + e]
-                        + a.A[(int64_t)((1 * BB + r) * BB + c) * a.nsys + e]
-                        + a.A[(int64_t)((2 * BB + r) * BB + c) * a.nsys + e];
+            for (int c = 0; c < BB; ++c) {
+                D[r][c] = A(0, r, c) + A(1, r, c) + A(2, r, c);
+                if (a.aos) D[r][c] += A(3, r, c);
+            }
         if (!tf_blk_inverse<BB>(D, Di)) *a.status = 1;
 #pragma unroll
         for (int r = 0; r < BB; ++r)
@@ -1151,13 +1170,14 @@ TF_DEVICE void tfk_top_body(const TfTopArgs& a, int e) {
         double Di[BB][BB], g[BB], x[BB];
 #pragma unroll
         for (int r = 0; r < BB; ++r) {
-            g[r] = a.rhs[(int64_t)r * a.nsys + e];
+            g[r] = a.aos ? a.rhs[(int64_t)e * 2 * BB + r] + a.rhs[(int64_t)e * 2 * BB + BB + r]
+                         : a.rhs[(int64_t)r * a.nsys + e];
 #pragma unroll
             for (int c = 0; c < BB; ++c) Di[r][c] = a.Ainv[(int64_t)(r * BB + c) * a.nsys + e];
         }
         tf_mv<BB>(x, Di, g);
 #pragma unroll
-        for (int r = 0; r < BB; ++r) a.x[(int64_t)r * a.nsys + e] = x[r];
+        for (int r = 0; r < BB; ++r) a.x[a.aos ? (int64_t)e * BB + r : (int64_t)r * a.nsys + e] = x[r];
     }
 }
 

@@ -67,6 +67,7 @@ struct Level {
     TfLayout L;
     int B = 0, MP = 0;
     DevBuf Ablk, rhs, x, Ut, Et, yt, tips_dn, tips_up, Dinv, Unup;
+    DevBuf crf, zt;        // cyclic-reduction levels (records per node, see TfLevelArgs)
 };
 
 }  // namespace
@@ -89,6 +90,7 @@ struct tf_solver {
     int64_t N = 0;
     int nsys = 1, periodic = 0, nstate = 3, refine = 0;
     TfLayout L1;
+    bool use_cr = false;   // reduced levels run the cyclic-reduction kernels (tfk_cr_*)
     tfb::Stream* stream = nullptr;
     int64_t bytes = 0;
 
@@ -104,7 +106,7 @@ struct tf_solver {
     double factor_c = 0.0;
     bool have_factor = false, have_jac = false;
     bool fact_checked = false, fact_needs_refine = false;   // refine == -1 (auto)
-    double last_omega = 0.0, refine_trigger = 1e-10;
+    double last_omega = 0.0, refine_trigger = 1e-11;
     // the backward-error check is a monitor: every factorisation while the matrix is new
     // (first 4, or c changed by > 10 %), then every berr_every-th one
     int berr_every = 8;
@@ -275,6 +277,7 @@ struct tf_solver {
         a.tips_dn = lv.tips_dn.p; a.tips_up = lv.tips_up.p;
         a.Lnext = nx.L; a.Anext = nx.Ablk.p; a.rhsnext = nx.rhs.p; a.xnext = nx.x.p;
         a.status = status;
+        a.next_aos = use_cr ? 1 : 0; a.crf = lv.crf.p; a.zt = lv.zt.p;
         return a;
     }
     // first level handled by the fused single-workgroup tail (levels.size() = none)
@@ -282,6 +285,7 @@ struct tf_solver {
     TfTopArgs top_args() {
         TfTopArgs t;
         t.nsys = nsys; t.A = top.Ablk.p; t.rhs = top.rhs.p; t.Ainv = topAinv.p; t.x = top.x.p; t.status = status;
+        t.aos = use_cr ? 1 : 0;
         return t;
     }
     void launch_tail(bool is_factor, const double* rhs1, double* x1) {
@@ -310,7 +314,12 @@ struct tf_solver {
             if (!fused) a.rhs = nullptr;
             unsigned gx = cdiv(a.L.Ptot, 64);
             if (l == 0) launch(fused ? TFK_L1_FACTOR_RHS : TFK_L1_FACTOR, gx, 2, 64, &a, sizeof(a));
-            else {
+            else if (use_cr) {
+                // one wavefront per chunk; leaves the next level's rows (and rhs) behind
+                a.cr_rhs = fused ? 1 : 0;
+                launch(TFK_CR_FACTOR, (unsigned)a.L.Ptot, 1, 64, &a, sizeof(a));
+                continue;
+            } else {
                 const int G = tfb::coop_group(levels[l]->B);
                 const unsigned gc = cdiv((int64_t)a.L.Ptot * G, 64);
                 const int ncols = levels[l]->B + (fused ? 1 : 0);
@@ -340,6 +349,7 @@ struct tf_solver {
         for (size_t l = tail_from; l-- > 0;) {
             TfLevelArgs a = level_args(l, rhs1, x1);
             if (l == 0) launch(TFK_L1_BACKSUB, cdiv(a.L.Ptot, 64), 1, 64, &a, sizeof(a));
+            else if (use_cr) launch(TFK_CR_BWD, (unsigned)a.L.Ptot, 1, 64, &a, sizeof(a));
             else launch(TFK_BT_BACKSUB, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
         }
     }
@@ -348,6 +358,7 @@ struct tf_solver {
             TfLevelArgs a = level_args(l, rhs1, x1);
             unsigned gx = cdiv(a.L.Ptot, 64);
             if (l == 0) launch(TFK_L1_SOLVE, gx, 2, 64, &a, sizeof(a));
+            else if (use_cr) { launch(TFK_CR_FWD, (unsigned)a.L.Ptot, 1, 64, &a, sizeof(a)); continue; }
             else launch(TFK_BT_RHS, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 2, 64, &a, sizeof(a));
             if (l == 0) launch(TFK_L1_ASM_RHS, gx, 1, 64, &a, sizeof(a));
             else launch(TFK_BT_ASM_RHS, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
@@ -494,24 +505,30 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
     mup = std::max(mup, 2);
     s->stream = tfb::stream_create();
 
-    // ---- level plan: chunk levels until a single chunk is left, then the top block
+    // ---- level plan: chunk levels until a single chunk is left, then the top block.
+    // Reduced levels: walks over chunks of m_upper nodes, or -- where the back end has
+    // them (3 <= b <= 8 on the GPU) -- cyclic reduction inside chunks of up to 16 nodes.
     const int b2 = sp.mp * sp.nvar;
+    s->use_cr = tfb::cyclic_reduction(b2);
     {
+        const int cr_len = opts && opts->m_upper > 0 ? std::min(std::max(opts->m_upper, 2), TF_CR_MAXLEN) : TF_CR_MAXLEN;
         int n = (int)N, B = sp.nvar, MP = sp.mp, m = m1;
+        bool first = true;
         while (true) {
             int P = std::max(1, n / m);
+            if (!first && s->use_cr) P = (n + cr_len - 1) / cr_len;     // chunk length <= cr_len
             std::unique_ptr<Level> lv(new Level());
             lv->L = make_layout(nsys, n, P, s->periodic);
             lv->B = B; lv->MP = MP;
             s->levels.push_back(std::move(lv));
             if (P == 1) break;
-            n = P; B = b2; MP = 1; m = mup;
+            n = P; B = b2; MP = 1; m = mup; first = false;
         }
         s->top.L = make_layout(nsys, 1, 1, s->periodic);
         s->top.B = b2; s->top.MP = 1;
     }
     {
-        const int tail_chunks = opts && opts->tail_chunks > 0 ? opts->tail_chunks : 0;
+        const int tail_chunks = opts && opts->tail_chunks > 0 && !s->use_cr ? opts->tail_chunks : 0;
         s->tail_from = s->levels.size();
         for (size_t l = 1; l < s->levels.size(); ++l)
             if (s->levels[l]->L.Ptot <= tail_chunks && s->levels.size() - l <= TF_MAX_TAIL) { s->tail_from = l; break; }
@@ -541,6 +558,16 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
         Level& lv = *s->levels[l];
         const int B = lv.B, MP = lv.MP;
         const int64_t pl = lv.L.plane;
+        if (l > 0 && s->use_cr) {
+            // records per node in natural order (TfLevelArgs)
+            const size_t nodes = (size_t)lv.L.N * nsys;
+            lv.Ablk.alloc(nodes * 4 * B * B, tot);
+            lv.rhs.alloc(nodes * 2 * B, tot);
+            lv.x.alloc(nodes * B, tot);
+            lv.crf.alloc(nodes * 5 * B * B, tot);
+            lv.zt.alloc(nodes * B, tot);
+            continue;
+        }
         // level 1 of a scalar model exchanges rows inside the band: U is 2*MP wide
         const int UW = (l == 0 && B == 1) ? 2 * MP : MP;
         lv.Ut.alloc((size_t)UW * B * B * pl, tot);
@@ -557,8 +584,8 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
             lv.x.alloc((size_t)B * pl, tot);
         }
     }
-    s->top.Ablk.alloc((size_t)3 * b2 * b2 * nsys, tot);
-    s->top.rhs.alloc((size_t)b2 * nsys, tot);
+    s->top.Ablk.alloc((size_t)4 * b2 * b2 * nsys, tot);
+    s->top.rhs.alloc((size_t)2 * b2 * nsys, tot);
     s->top.x.alloc((size_t)b2 * nsys, tot);
     s->topAinv.alloc((size_t)b2 * b2 * nsys, tot);
     *out = s.release();
