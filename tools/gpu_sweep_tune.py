@@ -17,9 +17,9 @@ if len(sys.argv) > 1 and sys.argv[1] == 'one':
     t = min(solver.eval_repeat(0, True, 50) for _ in range(3))
     tf_ = min(solver.eval_repeat(0, False, 50) for _ in range(3))
     nb = 8*(m._nvar*2 + len(m._J_sparse_array)) * fd['x'].size
-    print(json.dumps(dict(seg=os.environ.get('TRIFLOW_SWEEP_SEG'), block=os.environ.get('TRIFLOW_SWEEP_BLOCK'), nt=os.environ.get('TRIFLOW_SWEEP_NT'), m1=os.environ.get('M1'), fj_us=round(t*1e3,2), f_us=round(tf_*1e3,2), fj_TBs=round(nb/t/1e9,3))))
+    print(json.dumps(dict(seg=os.environ.get('TRIFLOW_SWEEP_SEG'), block=os.environ.get('TRIFLOW_SWEEP_BLOCK'), nt=os.environ.get('TRIFLOW_SWEEP_NT'), waves=os.environ.get('TRIFLOW_SWEEP_WAVES'), m1=os.environ.get('M1'), fj_us=round(t*1e3,2), f_us=round(tf_*1e3,2), fj_TBs=round(nb/t/1e9,3))))
 else:
-    for seg, block, nt, m1 in json.loads(os.environ['MATRIX']):
-        env = dict(os.environ, TRIFLOW_SWEEP_SEG=str(seg), TRIFLOW_SWEEP_BLOCK=str(block), TRIFLOW_SWEEP_NT=str(nt), M1=str(m1))
+    for seg, block, nt, m1, *rest in json.loads(os.environ['MATRIX']):
+        env = dict(os.environ, TRIFLOW_SWEEP_SEG=str(seg), TRIFLOW_SWEEP_BLOCK=str(block), TRIFLOW_SWEEP_NT=str(nt), M1=str(m1), TRIFLOW_SWEEP_WAVES=str(rest[0] if rest else 0))
         r = subprocess.run([sys.executable, __file__, 'one'], env=env, capture_output=True, text=True)
         print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:]); sys.stdout.flush()

@@ -115,11 +115,13 @@ def resource_usage(hsaco_path):
 def build_code_object(model, parvec_mask=0, seg=None, sweep_block=None):
     """Model -> (path of the cached gfx950 code object, spec dict)."""
     seg = seg or int(os.environ.get("TRIFLOW_SWEEP_SEG", "8"))
-    sweep_block = sweep_block or int(os.environ.get("TRIFLOW_SWEEP_BLOCK", "64"))
+    sweep_block = sweep_block or int(os.environ.get("TRIFLOW_SWEEP_BLOCK", "256"))
     body, spec = codegen.lower_model(model, parvec_mask=parvec_mask, seg=seg,
                                      sweep_block=sweep_block)
     nt = int(os.environ.get("TRIFLOW_SWEEP_NT", "0"))
-    source = _TU_HEAD % (_NT_STORE if nt else "") + body + _TU_TAIL
+    waves = int(os.environ.get("TRIFLOW_SWEEP_WAVES", "0"))
+    knobs = (_NT_STORE if nt else "") + ("#define TF_SWEEP_WAVES %d\n" % waves if waves else "")
+    source = _TU_HEAD % knobs + body + _TU_TAIL
     tag = codegen.source_hash(source, _skeleton_stamp(), " ".join(HIPCC_FLAGS), "elf")
     os.makedirs(CACHE_DIR, exist_ok=True)
     hsaco = os.path.join(CACHE_DIR, "model_%s.hsaco" % tag)

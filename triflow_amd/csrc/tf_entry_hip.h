@@ -11,6 +11,12 @@
 extern "C" {
 
 // ---- stencil sweeps: block (64,1,1), grid (chunks/64, segments) ------------
+// TF_SWEEP_WAVES (optional): occupancy the register allocator has to make room for
+#ifdef TF_SWEEP_WAVES
+#define TF_SWEEP_ATTR __attribute__((amdgpu_waves_per_eu(TF_SWEEP_WAVES)))
+#else
+#define TF_SWEEP_ATTR
+#endif
 __global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_sweep_f(TfSweepArgs a) {
     tfk_sweep_body<false>(a, TF_GID, blockIdx.y);
 }
@@ -18,7 +24,7 @@ __global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_sweep_f(TfSweepArgs a) {
 __global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_sweep_f_stage(TfSweepArgs a) {
     tfk_sweep_body<false, true>(a, TF_GID, blockIdx.y);
 }
-__global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_sweep_fj(TfSweepArgs a) {
+__global__ void TF_SWEEP_ATTR __launch_bounds__(TF_SWEEP_BLOCK) tfk_sweep_fj(TfSweepArgs a) {
     tfk_sweep_body<true>(a, TF_GID, blockIdx.y);
 }
 __global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_spmv(TfSpmvArgs a) {

@@ -525,14 +525,19 @@ struct TfRowsL1 {
         e = pg / a.L.P; p = pg - e * a.L.P;
         len = tf_len(a.L, p); start = tf_start(a.L, p);
     }
-    TF_DEVICE_M void load(int i, double (&row)[2 * TF_MP + 1][TF_NVAR][TF_NVAR]) const {
-#pragma unroll
-        for (int d = 0; d < TF_W; ++d) tf_blk_zero<TF_NVAR>(row[d]);
+    // the values of one block row as they lie in memory; requested ahead of their use
+    struct Raw { double jv[TF_NNZ > 0 ? TF_NNZ : 1]; };
+    TF_DEVICE_M void request(int i, Raw& r) const {
         const int64_t s = tf_idx(a.L, pg, i);
 #pragma unroll
+        for (int k = 0; k < TF_NNZ; ++k) r.jv[k] = a.Jv[(int64_t)k * a.L.plane + s];
+    }
+    TF_DEVICE_M void decode(int i, const Raw& raw, double (&row)[2 * TF_MP + 1][TF_NVAR][TF_NVAR]) const {
+#pragma unroll
+        for (int d = 0; d < TF_W; ++d) tf_blk_zero<TF_NVAR>(row[d]);
+#pragma unroll
         for (int k = 0; k < TF_NNZ; ++k)
-            row[tf_pat_off[k] + TF_MP][tf_pat_eq[k]][tf_pat_var[k]] =
-                -a.c * a.Jv[(int64_t)k * a.L.plane + s];
+            row[tf_pat_off[k] + TF_MP][tf_pat_eq[k]][tf_pat_var[k]] = -a.c * raw.jv[k];
         if (!a.L.periodic) {
             const int gl = start + i, gr = a.L.N - 1 - gl;
             if (gl < TF_MP) {
@@ -573,6 +578,11 @@ struct TfRowsL1 {
 #pragma unroll
         for (int r = 0; r < TF_NVAR; ++r) row[TF_MP][r][r] += 1.0;
     }
+    TF_DEVICE_M void load(int i, double (&row)[2 * TF_MP + 1][TF_NVAR][TF_NVAR]) const {
+        Raw raw;
+        request(i, raw);
+        decode(i, raw, row);
+    }
 };
 
 // level >= 2: explicit block-tridiagonal rows [3][b][b]
@@ -587,20 +597,30 @@ struct TfRowsBT {
         e = pg / a.L.P; p = pg - e * a.L.P;
         len = tf_len(a.L, p); start = tf_start(a.L, p);
     }
-    TF_DEVICE_M void load(int i, double (&row)[3][BB][BB]) const {
+    struct Raw { double blk[3][BB][BB]; };
+    TF_DEVICE_M void request(int i, Raw& r) const {
         const int64_t s = tf_idx(a.L, pg, i);
 #pragma unroll
         for (int d = 0; d < 3; ++d)
 #pragma unroll
-            for (int r = 0; r < BB; ++r)
+            for (int rr = 0; rr < BB; ++rr)
 #pragma unroll
                 for (int c = 0; c < BB; ++c)
-                    row[d][r][c] = a.Ablk[(int64_t)((d * BB + r) * BB + c) * a.L.plane + s];
+                    r.blk[d][rr][c] = a.Ablk[(int64_t)((d * BB + rr) * BB + c) * a.L.plane + s];
+    }
+    TF_DEVICE_M void decode(int i, const Raw& raw, double (&row)[3][BB][BB]) const {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) tf_blk_copy<BB>(row[d], raw.blk[d]);
         if (!a.L.periodic) {           // no neighbour beyond the ends
             const int g = start + i;
             if (g == 0) tf_blk_zero<BB>(row[0]);
             if (g == a.L.N - 1) tf_blk_zero<BB>(row[2]);
         }
+    }
+    TF_DEVICE_M void load(int i, double (&row)[3][BB][BB]) const {
+        Raw raw;
+        request(i, raw);
+        decode(i, raw, row);
     }
 };
 
@@ -633,7 +653,19 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
     double Eh[SPIKE ? MP : 1][SPIKE ? MP : 1][B][B];
     bool ok = true;
 
-    auto fetch = [&](int q, int jl) {              // local row jl into window slot q (pivot j = jl - q)
+    // Rows enter the window in local order 0, 1, 2, ...; their values are requested
+    // two rows ahead of their use so that the walk does not wait on memory per node.
+    struct Pre { typename Rows::Raw raw; double y[B]; };
+    auto request = [&](int jl, Pre& pre) {
+        if (jl < mI) {
+            const int i = node(jl);
+            rows.request(i, pre.raw);
+            const int64_t s = tf_idx(L, pg, i);
+#pragma unroll
+            for (int r = 0; r < B; ++r) pre.y[r] = a.rhs ? a.rhs[(int64_t)r * L.plane + s] : 0.0;
+        }
+    };
+    auto install = [&](int q, int jl, const Pre& pre) {   // local row jl into window slot q (pivot j = jl - q)
 #pragma unroll
         for (int c = 0; c < W; ++c) tf_blk_zero<B>(R[q][c]);
 #pragma unroll
@@ -644,8 +676,7 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
         }
         if (jl < mI) {
             double row[W][B][B];
-            const int i = node(jl);
-            rows.load(i, row);
+            rows.decode(node(jl), pre.raw, row);
 #pragma unroll
             for (int d = -MP; d <= MP; ++d) {
                 const int c = q + d;               // local column relative to the pivot
@@ -658,13 +689,20 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
                     if (t >= 0 && t < MP) tf_blk_copy<B>(Es[SPIKE ? q : 0][SPIKE ? t : 0], row[dd + MP]);
                 }
             }
-            const int64_t s = tf_idx(L, pg, i);
 #pragma unroll
-            for (int r = 0; r < B; ++r) y[q][r] = a.rhs ? a.rhs[(int64_t)r * L.plane + s] : 0.0;
+            for (int r = 0; r < B; ++r) y[q][r] = pre.y[r];
         }
     };
     // columns c < 0 only occur for the first MP local rows (jl + d < 0); there the
     // window slot q equals jl (pivot 0), so `c = q + d < 0` is exactly that case.
+    Pre pre0 = {}, pre1 = {};
+    request(0, pre0);
+    request(1, pre1);
+    auto fetch = [&](int q, int jl) {              // jl == next_row: rows are taken in order
+        install(q, jl, pre0);
+        pre0 = pre1;
+        request(jl + 2, pre1);
+    };
 
 #pragma unroll
     for (int q = 0; q < MP; ++q) fetch(q, q);
@@ -1104,8 +1142,8 @@ TF_DEVICE void tfk_backsub_body(const TfLevelArgs& a, int pg) {
 #pragma unroll
         for (int r = 0; r < B; ++r) a.x[(int64_t)r * L.plane + s] = xn[t][r];
     }
-    // the factors of node j-1 are requested before node j is processed, so one
-    // HBM latency is paid per chunk, not per node
+    // the factors of nodes j-1..j-3 are requested before node j is processed: one
+    // HBM latency is paid per chunk, not per node, with three nodes in flight
     struct Node { double y[B]; double U[UW][B][B]; double E[MP][B][B]; };
     auto load = [&](int j, Node& n) {
         const int64_t s = tf_idx(L, pg, j);
@@ -1121,10 +1159,11 @@ TF_DEVICE void tfk_backsub_body(const TfLevelArgs& a, int pg) {
                     if (c < MP) n.E[c < MP ? c : 0][r][k] = a.Et[(int64_t)((c * B + r) * B + k) * L.plane + s];
                 }
     };
-    Node cur, nxt;
+    Node cur = {}, nx1 = {}, nx2 = {};
     load(mI - 1, cur);
+    if (mI > 1) load(mI - 2, nx1);
+    if (mI > 2) load(mI - 3, nx2);
     for (int j = mI - 1; j >= 0; --j) {
-        if (j > 0) load(j - 1, nxt);
         const int64_t s = tf_idx(L, pg, j);
         double x[B];
 #pragma unroll
@@ -1133,13 +1172,15 @@ TF_DEVICE void tfk_backsub_body(const TfLevelArgs& a, int pg) {
         for (int c = 0; c < UW; ++c) tf_mv_sub<B>(x, cur.U[c], xn[c]);
 #pragma unroll
         for (int c = 0; c < MP; ++c) tf_mv_sub<B>(x, cur.E[c], sa[c]);
+        cur = nx1;
+        nx1 = nx2;
+        if (j > 2) load(j - 3, nx2);
 #pragma unroll
         for (int c = UW - 1; c > 0; --c)
 #pragma unroll
             for (int r = 0; r < B; ++r) xn[c][r] = xn[c - 1][r];
 #pragma unroll
         for (int r = 0; r < B; ++r) { xn[0][r] = x[r]; a.x[(int64_t)r * L.plane + s] = x[r]; }
-        cur = nxt;
     }
 }
 
