@@ -36,6 +36,31 @@ __global__ void __launch_bounds__(256) planes_walk(const double* __restrict__ in
         for (int k = 0; k < NW; ++k) out[k * n + i] = acc + k;
     }
 }
+// level-1 back-substitution pattern: few threads (one per chunk), each walking `rows`
+// nodes upwards, NR planes read and NW written per node, next node requested ahead
+template <int NR, int NW>
+__global__ void __launch_bounds__(64) chunk_walk(const double* __restrict__ in, double* __restrict__ out, long n, int stride, int rows) {
+    const long col = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= stride) return;
+    double cur[NR], nxt[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) cur[k] = in[k * n + (long)(rows - 1) * stride + col];
+    double carry = 0.0;
+    for (int r = rows - 1; r >= 0; --r) {
+        if (r > 0) {
+#pragma unroll
+            for (int k = 0; k < NR; ++k) nxt[k] = in[k * n + (long)(r - 1) * stride + col];
+        }
+        double acc = carry;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) acc = fma(cur[k], 1.0000001, acc);
+        carry = acc * 0.5;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) out[k * n + (long)r * stride + col] = acc + k;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) cur[k] = nxt[k];
+    }
+}
 __global__ void __launch_bounds__(256) fill2(double2* __restrict__ out, long n2) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x)
         out[i] = make_double2(1.0, 2.0);
@@ -86,6 +111,20 @@ int main() {
         ms = time_ms([&] { planes_walk<3, 25><<<g2, blk>>>(in, out, n, stride, seg); });
         char nm[64]; snprintf(nm, 64, "planes_walk r3 w25 seg=%d", seg);
         report(nm, 28.0 * n * 8, ms);
+    }
+    CK(hipFree(in)); CK(hipFree(out));
+    CK(hipMalloc(&in, 40 * n * 8)); CK(hipMalloc(&out, 32 * n * 8));
+    CK(hipMemset(in, 0, 40 * n * 8)); CK(hipMemset(out, 0, 32 * n * 8));
+    CK(hipDeviceSynchronize());
+    for (int rows : {32, 16, 8}) {
+        const int stride = (int)(n / rows);
+        const int g2 = (stride + 63) / 64;
+        ms = time_ms([&] { chunk_walk<39, 3><<<g2, 64>>>(in, out, n, stride, rows); });
+        char nm[64]; snprintf(nm, 64, "chunk_walk r39 w3, %d threads x %d rows", stride, rows);
+        report(nm, 42.0 * n * 8, ms);
+        ms = time_ms([&] { chunk_walk<22, 3><<<g2, 64>>>(in, out, n, stride, rows); });
+        snprintf(nm, 64, "chunk_walk r22 w3, %d threads x %d rows", stride, rows);
+        report(nm, 25.0 * n * 8, ms);
     }
     const long n2 = 25 * n / 2;
     for (int g : {2048, 8192, 32768}) {

@@ -807,3 +807,33 @@ __device__ __forceinline__ void tfk_cr_bwd_coop(const TfLevelArgs& a) {
         }
     }
 }
+
+// ---- top block: one group of 8 lanes inverts the b x b system of one ensemble member
+template <int BB>
+__device__ __forceinline__ void tfk_top_factor_coop(const TfTopArgs& a) {
+    constexpr int G = 8, NGRP = 8;
+    const int grp = threadIdx.x / G, g = threadIdx.x % G;
+    const int e = blockIdx.x * NGRP + grp;
+    const bool on = e < a.nsys && g < BB;
+    const int es = e < a.nsys ? e : 0, gq = g < BB ? g : 0;
+    __shared__ double sX[NGRP * 2 * G * (2 * BB + 1)];
+    double S[BB], INV[BB];
+#pragma unroll
+    for (int c = 0; c < BB; ++c) {
+        if (a.aos) {
+            const double* rec = a.A + (int64_t)es * 4 * BB * BB + gq * BB + c;
+            S[c] = rec[0] + rec[BB * BB] + rec[2 * BB * BB] + rec[3 * BB * BB];
+        } else {
+            S[c] = a.A[(int64_t)((0 * BB + gq) * BB + c) * a.nsys + es]
+                 + a.A[(int64_t)((1 * BB + gq) * BB + c) * a.nsys + es]
+                 + a.A[(int64_t)((2 * BB + gq) * BB + c) * a.nsys + es];
+        }
+    }
+    bool ok = true;
+    const int myk = tf_gj_coop<BB, G>(S, INV, on, g, sX + grp * 2 * G * (2 * BB + 1), ok);
+    if (on) {
+#pragma unroll
+        for (int c = 0; c < BB; ++c) a.Ainv[(int64_t)(myk * BB + c) * a.nsys + e] = INV[c];
+        if (!ok) *a.status = 1;
+    }
+}

@@ -150,7 +150,10 @@ __global__ void __launch_bounds__(64) tfk_bt_backsub(TfLevelArgs a) {
     if constexpr (TfCoop<TF_B2>::G > 1) tfk_bt_backsub_coop<TF_B2>(a);
     else tfk_backsub_body<TfRowsUp>(a, TF_GID);
 }
-__global__ void __launch_bounds__(64) tfk_top_factor(TfTopArgs a) { tfk_top_body<TF_B2, true>(a, TF_GID); }
+__global__ void __launch_bounds__(64) tfk_top_factor(TfTopArgs a) {
+    if constexpr (TfCoop<TF_B2>::G == 8) tfk_top_factor_coop<TF_B2>(a);       // 8 lanes per member
+    else tfk_top_body<TF_B2, true>(a, TF_GID);
+}
 __global__ void __launch_bounds__(64) tfk_top_solve(TfTopArgs a) { tfk_top_body<TF_B2, false>(a, TF_GID); }
 
 // ---- cyclic-reduction levels (tf_coop_hip.h): one wavefront per chunk, 3 <= b <= 8

@@ -331,7 +331,7 @@ struct tf_solver {
             else launch(TFK_BT_ASM_MAT, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
         }
         if (tail_from < levels.size()) launch_tail(true, nullptr, nullptr);
-        else { TfTopArgs t = top_args(); launch(TFK_TOP_FACTOR, cdiv(nsys, 64), 1, 64, &t, sizeof(t)); }
+        else { TfTopArgs t = top_args(); launch(TFK_TOP_FACTOR, cdiv((int64_t)nsys * (tfb::coop_group(top.B) == 8 ? 8 : 1), 64), 1, 64, &t, sizeof(t)); }
         have_factor = true;
         ++n_factor;
         const bool c_moved = std::fabs(c - checked_c) > 0.1 * std::fabs(checked_c);
