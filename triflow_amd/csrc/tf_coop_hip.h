@@ -289,11 +289,11 @@ __device__ __forceinline__ void tfk_bt_backsub_coop(const TfLevelArgs& a) {
     if (lane_on) {
         int p2, i2;
         tf_locate(a.Lnext, p, p2, i2);
-        const double xs = a.xnext[(int64_t)g * a.Lnext.plane + tf_idx(a.Lnext, e * a.Lnext.P + p2, i2)];
+        const double xs = a.xnext[tf_next_x(a, e, p, tf_idx(a.Lnext, e * a.Lnext.P + p2, i2), g, BB)];
         tf_locate(a.Lnext, pa, p2, i2);
         sX[grp][g] = xs;
         sA[grp][g] = has_above
-            ? a.xnext[(int64_t)g * a.Lnext.plane + tf_idx(a.Lnext, e * a.Lnext.P + p2, i2)] : 0.0;
+            ? a.xnext[tf_next_x(a, e, pa, tf_idx(a.Lnext, e * a.Lnext.P + p2, i2), g, BB)] : 0.0;
         a.x[(int64_t)g * L.plane + tf_idx(L, pg, mI)] = xs;
     }
     struct Node { double U[BB]; double E[BB]; double y; };
@@ -371,7 +371,7 @@ __device__ __forceinline__ void tfk_bt_asm_coop(const TfLevelArgs& a) {
 #pragma unroll
         for (int k = 0; k < BB; ++k) rg = tf_fma(-K[k], tup(Tip::y(0, k)), rg);
     }
-    a.rhsnext[(int64_t)g * a.Lnext.plane + s2] = rg;
+    a.rhsnext[tf_next_rhs(a, e, p, s2, g, BB)] = rg;
     if (MATRIX) {
 #pragma unroll
         for (int c = 0; c < BB; ++c) {
@@ -389,9 +389,9 @@ __device__ __forceinline__ void tfk_bt_asm_coop(const TfLevelArgs& a) {
                     sup = tf_fma(-K[k], tup(Tip::W(0, 0, k, c)), sup);
                 }
             }
-            a.Anext[(int64_t)((0 * BB + g) * BB + c) * a.Lnext.plane + s2] = sub;
-            a.Anext[(int64_t)((1 * BB + g) * BB + c) * a.Lnext.plane + s2] = dia;
-            a.Anext[(int64_t)((2 * BB + g) * BB + c) * a.Lnext.plane + s2] = sup;
+            a.Anext[tf_next_A(a, e, p, s2, 0, g, c, BB)] = sub;
+            a.Anext[tf_next_A(a, e, p, s2, 1, g, c, BB)] = dia;
+            a.Anext[tf_next_A(a, e, p, s2, 2, g, c, BB)] = sup;
         }
     }
 }

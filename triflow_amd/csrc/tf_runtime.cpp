@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -66,6 +67,7 @@ struct DevBuf {
 struct Level {
     TfLayout L;
     int B = 0, MP = 0;
+    bool cr = false;       // cyclic-reduction level (tfk_cr_*), else chunk walks
     DevBuf Ablk, rhs, x, Ut, Et, yt, tips_dn, tips_up, Dinv, Unup;
     DevBuf crf, zt;        // cyclic-reduction levels (records per node, see TfLevelArgs)
 };
@@ -90,7 +92,11 @@ struct tf_solver {
     int64_t N = 0;
     int nsys = 1, periodic = 0, nstate = 3, refine = 0;
     TfLayout L1;
-    bool use_cr = false;   // reduced levels run the cyclic-reduction kernels (tfk_cr_*)
+    bool use_cr = false;   // the back end has the cyclic-reduction kernels (tfk_cr_*) for this block size
+    // storage of what a level hands to the next one: records per node (below a cyclic-
+    // reduction level) or partition-interleaved planes
+    bool level_cr(size_t l) const { return l < levels.size() && levels[l]->cr; }
+    bool next_aos(size_t l) const { return l + 1 < levels.size() ? levels[l + 1]->cr : levels.back()->cr; }
     tfb::Stream* stream = nullptr;
     int64_t bytes = 0;
 
@@ -277,7 +283,7 @@ struct tf_solver {
         a.tips_dn = lv.tips_dn.p; a.tips_up = lv.tips_up.p;
         a.Lnext = nx.L; a.Anext = nx.Ablk.p; a.rhsnext = nx.rhs.p; a.xnext = nx.x.p;
         a.status = status;
-        a.next_aos = use_cr ? 1 : 0; a.crf = lv.crf.p; a.zt = lv.zt.p;
+        a.next_aos = next_aos(l) ? 1 : 0; a.crf = lv.crf.p; a.zt = lv.zt.p;
         return a;
     }
     // first level handled by the fused single-workgroup tail (levels.size() = none)
@@ -285,7 +291,7 @@ struct tf_solver {
     TfTopArgs top_args() {
         TfTopArgs t;
         t.nsys = nsys; t.A = top.Ablk.p; t.rhs = top.rhs.p; t.Ainv = topAinv.p; t.x = top.x.p; t.status = status;
-        t.aos = use_cr ? 1 : 0;
+        t.aos = levels.back()->cr ? 1 : 0;
         return t;
     }
     void launch_tail(bool is_factor, const double* rhs1, double* x1) {
@@ -314,7 +320,7 @@ struct tf_solver {
             if (!fused) a.rhs = nullptr;
             unsigned gx = cdiv(a.L.Ptot, 64);
             if (l == 0) launch(fused ? TFK_L1_FACTOR_RHS : TFK_L1_FACTOR, gx, 2, 64, &a, sizeof(a));
-            else if (use_cr) {
+            else if (levels[l]->cr) {
                 // one wavefront per chunk; leaves the next level's rows (and rhs) behind
                 a.cr_rhs = fused ? 1 : 0;
                 launch(TFK_CR_FACTOR, (unsigned)a.L.Ptot, 1, 64, &a, sizeof(a));
@@ -349,7 +355,7 @@ struct tf_solver {
         for (size_t l = tail_from; l-- > 0;) {
             TfLevelArgs a = level_args(l, rhs1, x1);
             if (l == 0) launch(TFK_L1_BACKSUB, cdiv(a.L.Ptot, 64), 1, 64, &a, sizeof(a));
-            else if (use_cr) launch(TFK_CR_BWD, (unsigned)a.L.Ptot, 1, 64, &a, sizeof(a));
+            else if (levels[l]->cr) launch(TFK_CR_BWD, (unsigned)a.L.Ptot, 1, 64, &a, sizeof(a));
             else launch(TFK_BT_BACKSUB, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
         }
     }
@@ -358,7 +364,7 @@ struct tf_solver {
             TfLevelArgs a = level_args(l, rhs1, x1);
             unsigned gx = cdiv(a.L.Ptot, 64);
             if (l == 0) launch(TFK_L1_SOLVE, gx, 2, 64, &a, sizeof(a));
-            else if (use_cr) { launch(TFK_CR_FWD, (unsigned)a.L.Ptot, 1, 64, &a, sizeof(a)); continue; }
+            else if (levels[l]->cr) { launch(TFK_CR_FWD, (unsigned)a.L.Ptot, 1, 64, &a, sizeof(a)); continue; }
             else launch(TFK_BT_RHS, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 2, 64, &a, sizeof(a));
             if (l == 0) launch(TFK_L1_ASM_RHS, gx, 1, 64, &a, sizeof(a));
             else launch(TFK_BT_ASM_RHS, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
@@ -511,15 +517,22 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
     const int b2 = sp.mp * sp.nvar;
     s->use_cr = tfb::cyclic_reduction(b2);
     {
+        // Cyclic reduction pays where a level is latency-bound (few chunks): one wavefront
+        // per 16-node chunk does about twice the arithmetic of the walks (later rounds leave
+        // lanes idle).  Levels with more nodes than cr_max_nodes (all ensemble members
+        // together; ~10 wavefronts per CU, scanned with tools/gpu_cr_scan.sh) keep the walks.
         const int cr_len = opts && opts->m_upper > 0 ? std::min(std::max(opts->m_upper, 2), TF_CR_MAXLEN) : TF_CR_MAXLEN;
+        int64_t cr_max_nodes = 40000;
+        if (const char* v = getenv("TRIFLOW_CR_MAX_NODES")) cr_max_nodes = atoll(v);
         int n = (int)N, B = sp.nvar, MP = sp.mp, m = m1;
         bool first = true;
         while (true) {
+            const bool cr = !first && s->use_cr && (int64_t)n * nsys <= cr_max_nodes;
             int P = std::max(1, n / m);
-            if (!first && s->use_cr) P = (n + cr_len - 1) / cr_len;     // chunk length <= cr_len
+            if (cr) P = (n + cr_len - 1) / cr_len;                 // chunk length <= cr_len
             std::unique_ptr<Level> lv(new Level());
             lv->L = make_layout(nsys, n, P, s->periodic);
-            lv->B = B; lv->MP = MP;
+            lv->B = B; lv->MP = MP; lv->cr = cr;
             s->levels.push_back(std::move(lv));
             if (P == 1) break;
             n = P; B = b2; MP = 1; m = mup; first = false;
@@ -528,7 +541,8 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
         s->top.B = b2; s->top.MP = 1;
     }
     {
-        const int tail_chunks = opts && opts->tail_chunks > 0 && !s->use_cr ? opts->tail_chunks : 0;
+        const bool any_cr = s->levels.back()->cr;
+        const int tail_chunks = opts && opts->tail_chunks > 0 && !any_cr ? opts->tail_chunks : 0;
         s->tail_from = s->levels.size();
         for (size_t l = 1; l < s->levels.size(); ++l)
             if (s->levels[l]->L.Ptot <= tail_chunks && s->levels.size() - l <= TF_MAX_TAIL) { s->tail_from = l; break; }
@@ -558,7 +572,7 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
         Level& lv = *s->levels[l];
         const int B = lv.B, MP = lv.MP;
         const int64_t pl = lv.L.plane;
-        if (l > 0 && s->use_cr) {
+        if (lv.cr) {
             // records per node in natural order (TfLevelArgs)
             const size_t nodes = (size_t)lv.L.N * nsys;
             lv.Ablk.alloc(nodes * 4 * B * B, tot);
