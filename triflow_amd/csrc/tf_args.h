@@ -43,6 +43,7 @@ struct TfSweepArgs {               // F / F+J stencil sweep, J @ v, A-row build
     int nterms;
     const double* kx[TF_MAX_TERMS];
     double kc[TF_MAX_TERMS];
+    double fscale;                 // F is stored as fscale * F (dt * F: the first stage's right-hand side)
 };
 
 struct TfSpmvArgs {                // y = scale * J @ v  (clamped/wrapped columns)

@@ -136,7 +136,7 @@ TF_DEVICE void tfk_sweep_body(const TfSweepArgs& a, int pg, int seg) {
             double Fo[TF_NVAR];
             tf_eval_F(w, par, dx, xc, Fo);
 #pragma unroll
-            for (int v = 0; v < TF_NVAR; ++v) TF_STORE_STREAM(&a.F[(int64_t)v * L.plane + s], Fo[v]);
+            for (int v = 0; v < TF_NVAR; ++v) TF_STORE_STREAM(&a.F[(int64_t)v * L.plane + s], a.fscale * Fo[v]);
             if (WITH_J) {
                 double Jo[TF_NNZ > 0 ? TF_NNZ : 1];
                 tf_eval_J(w, par, dx, xc, Jo);

@@ -235,10 +235,10 @@ struct tf_solver {
     }
 
     void sweep(const double* fields, bool with_j, int nterms = 0, const double* const* kx = nullptr,
-               const double* kc = nullptr) {
+               const double* kc = nullptr, double fscale = 1.0) {
         TfSweepArgs a;
         std::memset(&a, 0, sizeof(a));
-        a.nterms = nterms;
+        a.nterms = nterms; a.fscale = fscale;
         for (int t = 0; t < nterms; ++t) { a.kx[t] = kx[t]; a.kc[t] = kc[t]; }
         a.L = L1; a.fields = fields; a.helpers = helpers.p; a.parvec = parvec.p; a.parsca = parsca.p;
         a.dx = dx.p; a.xcoord = xcoord.p; a.F = F.p; a.Jv = Jv.p; a.with_j = with_j ? 1 : 0;
@@ -267,6 +267,15 @@ struct tf_solver {
         a.addF = Fp; a.cF = cF; a.cA = cA;
         unsigned gx = cdiv(L1.Ptot, spec.sweep_block), gy = cdiv(L1.M, spec.seg);
         launch(TFK_SPMV, gx, gy, spec.sweep_block, &a, sizeof(a));
+    }
+
+    // State a step starts from: the reference copies the fields and applies the hook to
+    // the copy (schemes.py:144-145, 548-549); without a hook the source slot is read in place.
+    const double* stage_input(int src, double* U) {
+        if (ndir == 0) return st(src);
+        tfb::d2d(U, st(src), (size_t)vecn() * sizeof(double), stream);
+        apply_dirichlet(U);
+        return U;
     }
 
     // -------------------------------------------------------- banded solver
@@ -805,16 +814,13 @@ int tf_step_theta(tf_solver* s, int32_t src, int32_t dst, double dt, double thet
     require(s, "null solver");
     require(src != dst, "tf_step_theta: src and dst slots must differ");
     double* U = s->st(dst);
-    tfb::d2d(U, s->st(src), (size_t)s->vecn() * sizeof(double), s->stream);
-    s->apply_dirichlet(U);
-    s->sweep(U, true);
-    s->spmv(U, s->Wjv.p, theta);                                   // (theta*J) @ U
-    const double* xs[3] = {s->F.p, s->Wjv.p, U};
+    const double* Uin = s->stage_input(src, U);                    // copy + hook only when there is a hook
+    s->sweep(Uin, true);
+    s->spmv(Uin, s->Wjv.p, theta);                                 // (theta*J) @ U
+    const double* xs[3] = {s->F.p, s->Wjv.p, Uin};
     const double cs[3] = {dt, 0, 0};
     s->vec(TF_VEC_THETA_RHS, s->Wrhs.p, nullptr, 3, xs, cs);       // dt*(F - .) + U
-    s->factor(theta * dt, s->Wrhs.p, s->Wstage.p);
-    const double* cp[1] = {s->Wstage.p};
-    s->vec(TF_VEC_COPY, U, nullptr, 1, cp, nullptr);
+    s->factor(theta * dt, s->Wrhs.p, U);
     s->apply_dirichlet(U, true);
     TF_API_END
 }
@@ -828,29 +834,24 @@ int tf_step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns,
     require(ns >= 1 && ns <= 6, "tf_step_row: 1 <= s <= 6");
     require(src != dst, "tf_step_row: src and dst slots must differ");
     double* U = s->st(dst);
-    tfb::d2d(U, s->st(src), (size_t)s->vecn() * sizeof(double), s->stream);
-    s->apply_dirichlet(U);
-    s->sweep(U, true);                         // J(U) and F(U) = F of stage 0
+    const double* Uin = s->stage_input(src, U);
+    s->sweep(Uin, true, 0, nullptr, nullptr, dt);   // J(U) and dt*F(U): right-hand side of stage 0
     const double* ks[TF_MAX_TERMS];
     double cs[TF_MAX_TERMS];
     for (int i = 0; i < ns; ++i) {
         if (i > 0) {
             // F(U + sum_j alpha_ij k_j): the stage state is formed inside the sweep
             for (int j = 0; j < i; ++j) { ks[j] = s->K[j].p; cs[j] = alpha[i * ns + j]; }
-            s->sweep(U, false, i, ks, cs);
+            s->sweep(Uin, false, i, ks, cs);
             // dt*F + dt*(J @ sum_j gamma_ij k_j) in one pass over J
             for (int j = 0; j < i; ++j) cs[j] = gamma[i * ns + j];
             s->spmv_stage(i, ks, cs, s->F.p, dt, dt, s->Wrhs.p);
-        } else {
-            const double* xs[1] = {s->F.p};
-            const double c1[1] = {dt};
-            s->vec(TF_VEC_SUM, s->Wrhs.p, nullptr, 1, xs, c1);     // dt*F
         }
-        if (i == 0) s->factor(gamma[0] * dt, s->Wrhs.p, s->K[0].p);   // factorise + first stage
+        if (i == 0) s->factor(gamma[0] * dt, s->F.p, s->K[0].p);      // factorise + first stage
         else s->solve(s->Wrhs.p, s->K[i].p);
     }
     for (int j = 0; j < ns; ++j) { ks[j] = s->K[j].p; cs[j] = b[j]; }
-    s->vec(TF_VEC_SUM, U, U, ns, ks, cs);                          // U + sum_i b_i k_i
+    s->vec(TF_VEC_SUM, U, Uin, ns, ks, cs);                        // U + sum_i b_i k_i
     if (b_pred && err_out) {
         tfb::memset0(s->red.p, sizeof(double), s->stream);
         for (int j = 0; j < ns; ++j) cs[j] = b_pred[j];
@@ -877,26 +878,23 @@ int tf_step_bdf2(tf_solver* s, int32_t src, int32_t dst, double dt) {
     require(s, "null solver");
     require(src != dst, "tf_step_bdf2: src and dst slots must differ");
     double* U = s->st(dst);
-    tfb::d2d(U, s->st(src), (size_t)s->vecn() * sizeof(double), s->stream);
-    s->apply_dirichlet(U);
-    s->sweep(U, true);
+    const double* Uin = s->stage_input(src, U);
     const bool two_step = s->bdf_have_prev &&
         std::fabs(s->bdf_dt_prev - dt) <= 1e-12 * std::fabs(dt);
+    s->sweep(Uin, true, 0, nullptr, nullptr, two_step ? 1.0 : dt);
+    const double* rhs = s->F.p;                                    // dt*F on a first step
     if (two_step) {
-        const double* xs[3] = {U, s->Uprev.p, s->F.p};
+        const double* xs[3] = {Uin, s->Uprev.p, s->F.p};
         const double cs[3] = {1.0 / 3.0, (2.0 / 3.0) * dt, 0};
         s->vec(TF_VEC_BDF2_RHS, s->Wrhs.p, nullptr, 3, xs, cs);
-    } else {
-        const double* xs[1] = {s->F.p};
-        const double c1[1] = {dt};
-        s->vec(TF_VEC_SUM, s->Wrhs.p, nullptr, 1, xs, c1);
+        rhs = s->Wrhs.p;
     }
-    const double* cp[1] = {U};
+    const double* cp[1] = {Uin};
     s->vec(TF_VEC_COPY, s->Uprev.p, nullptr, 1, cp, nullptr);
     s->bdf_have_prev = true;
     s->bdf_dt_prev = dt;
-    s->factor(two_step ? (2.0 / 3.0) * dt : dt, s->Wrhs.p, s->Wdel.p);
-    const double* ys[2] = {U, s->Wdel.p};
+    s->factor(two_step ? (2.0 / 3.0) * dt : dt, rhs, s->Wdel.p);
+    const double* ys[2] = {Uin, s->Wdel.p};
     s->vec(TF_VEC_ADD, U, nullptr, 2, ys, nullptr);
     s->apply_dirichlet(U, true);
     TF_API_END
