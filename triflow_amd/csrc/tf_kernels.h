@@ -624,6 +624,10 @@ struct TfRowsBT {
     }
 };
 
+#ifndef TF_PREFETCH_DEEP
+#define TF_PREFETCH_DEEP(spike) (!(spike))
+#endif
+
 // ---- interior elimination of one chunk in one direction --------------------
 // DIR = +1 walks down (local j <-> node j), DIR = -1 walks up (local j <-> node
 // mI-1-j, offsets mirrored).  SPIKE: also carry the coupling to the separator
@@ -695,13 +699,15 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
     };
     // columns c < 0 only occur for the first MP local rows (jl + d < 0); there the
     // window slot q equals jl (pivot 0), so `c = q + d < 0` is exactly that case.
+    // (one row ahead in the factor walks, whose spike columns leave no registers for two)
+    constexpr bool DEEP = TF_PREFETCH_DEEP(SPIKE);
     Pre pre0 = {}, pre1 = {};
     request(0, pre0);
-    request(1, pre1);
+    if (DEEP) request(1, pre1);
     auto fetch = [&](int q, int jl) {              // jl == next_row: rows are taken in order
         install(q, jl, pre0);
-        pre0 = pre1;
-        request(jl + 2, pre1);
+        if (DEEP) { pre0 = pre1; request(jl + 2, pre1); }
+        else request(jl + 1, pre0);
     };
 
 #pragma unroll
