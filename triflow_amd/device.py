@@ -145,7 +145,7 @@ class Stepper:
         return slot
 
     def resident_slot(self, fields):
-        b = fields._device_backing()
+        b = _backing_of(fields)
         if b is not None and b.stepper is self and b.valid():
             return b.slot
         return None
@@ -163,6 +163,12 @@ class Stepper:
     def wrap(self, template, slot):
         """New container for the state in ``slot`` (coordinates and help functions
         shared with ``template`` until it is read)."""
+        if not hasattr(template, "_device_child"):
+            # a container of another package (the reference's xarray-based Fields):
+            # its protocol is copy() + fill(uflat) (fields.py:122-183)
+            new = template.copy()
+            new.fill(self.solver.get_state_flat(slot)[0])
+            return new
         new = template._device_child(DeviceBacking(self, slot, self.slot_version[slot]))
         self._users[slot].append(weakref.ref(new))
         return new
@@ -209,14 +215,23 @@ class Stepper:
         self._dirichlet = key
 
 
+def _backing_of(fields):
+    probe = getattr(fields, "_device_backing", None)
+    return probe() if probe is not None else None
+
+
 def stepper_for(model, fields, pars, **opts):
     """The Stepper matching ``fields`` / ``pars`` (cached on the compiled model)."""
     compiled = getattr(model, "_device", None)
     if compiled is None:
+        # a Model class of another package compiled with ``compiler=hip_compiler``:
+        # the plugin's F function carries the device side (routines.py:11 keeps it as _ufunc)
+        compiled = getattr(getattr(getattr(model, "F", None), "_ufunc", None), "device_model", None)
+    if compiled is None:
         raise RuntimeError(
             "this scheme runs on the GPU and needs a model compiled with the HIP "
             "compiler (Model(..., compiler='hip')); got a model without device code")
-    b = fields._device_backing()
+    b = _backing_of(fields)
     if b is not None and b.valid() and b.stepper.compiled is compiled:
         return b.stepper
     values = [pars[k] for k in compiled.pars]

@@ -71,7 +71,8 @@ def _device_step(model, t, fields, pars, hook, launch, dt=None):
 def _difference_norms(a, b, ord):
     """``||a[var] - b[var]||_ord`` for every dependent variable; computed by a
     reduction kernel when both containers still live on the same GPU solver."""
-    ba, bb = a._device_backing(), b._device_backing()
+    probe = lambda f: getattr(f, "_device_backing", lambda: None)()   # foreign containers: host norms
+    ba, bb = probe(a), probe(b)
     if ba is not None and bb is not None and ba.stepper is bb.stepper \
             and ba.valid() and bb.valid() and ord in (2, np.inf):
         return list(ba.stepper.solver.diff_norms(ba.slot, bb.slot, ord)[0])
