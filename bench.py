@@ -60,11 +60,9 @@ def build_problem(cfg, N, table):
     return name, fd["x"], fields, pars, dt, scheme
 
 
-def cpu_baseline(cfg, N, scheme_name, fair=False):
-    """The reference's algorithm (oracle = NumPy/SciPy port of the numpy-compiler
-    path + SuperLU) on this box's host cores, full size, single thread.  ``fair``:
-    the same arithmetic without the reference's per-row ``np.stack`` interleave
-    (compilers.py:288), so that the comparison is not inflated by that pathology."""
+def _cpu_sample(job):
+    """One worker of the CPU baseline: `nsteps` steps of one member; returns seconds."""
+    cfg, N, scheme_name, fair, nsteps = job
     from oracle import numpy_path as ora          # the checker, timed as the CPU baseline
     from triflow_amd import Model, workloads
     name, fd, pars, dt, _ = workloads.config_inputs(cfg, N)
@@ -73,14 +71,35 @@ def cpu_baseline(cfg, N, scheme_name, fair=False):
     scheme = {"ROS2": ora.ROS2, "RODASPR": lambda m: ora.RODASPR(m, time_stepping=False),
               "Theta": ora.Theta, "BDF2": ora.BDF2}[scheme_name](model)
     fields = model.fields_template(**fd)
-    nsteps, t = (2 if fair else 3), 0.0
+    t = 0.0
     t0 = time.perf_counter()
     for _ in range(nsteps):
         t, fields = scheme(t, fields, dt, pars)
-    el = time.perf_counter() - t0
-    return dict(value=nsteps / el, unit="steps/s", cores=1, kind="port",
-                sample="%d %s steps of the same workload (N=%d), NumPy %s / SciPy SuperLU, "
-                       "single thread, %.1f s" % (nsteps, scheme_name, N, np.__version__, el))
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(cfg, N, scheme_name, fair=False, workers=1):
+    """The reference's algorithm (oracle = NumPy/SciPy port of the numpy-compiler
+    path + SuperLU) on this box's host cores, full size.  The algorithm is single
+    threaded by construction; ``workers`` > 1 integrates that many independent
+    ensemble members in parallel processes (the reference's own advice for sweeps,
+    user_guide.rst:125-138) and reports their aggregate rate.  ``fair``: the same
+    arithmetic without the reference's per-row ``np.stack`` interleave
+    (compilers.py:288), so that the comparison is not inflated by that pathology."""
+    nsteps = 2 if fair else 3
+    job = (cfg, N, scheme_name, fair, nsteps)
+    if workers <= 1:
+        el = _cpu_sample(job)
+    else:
+        import multiprocessing as mp
+        with mp.get_context("spawn").Pool(workers) as pool:
+            el = max(pool.map(_cpu_sample, [job] * workers))       # slowest member, stepping only
+    return dict(value=max(workers, 1) * nsteps / el, unit="steps/s", cores=max(workers, 1), kind="port",
+                sample="%d %s steps of the same workload (N=%d)%s, NumPy %s / SciPy SuperLU, "
+                       "%s, %.1f s" % (nsteps, scheme_name, N,
+                                       " by each of %d member processes" % workers if workers > 1 else "",
+                                       np.__version__,
+                                       "one thread per member" if workers > 1 else "single thread", el))
 
 
 def scheme_api_rate(model, cfg, N, scheme_name, dt, steps=20):
@@ -112,6 +131,8 @@ def main():
     ap.add_argument("--nodes", type=int, default=0, help="override N (default: BASELINE size)")
     ap.add_argument("--scheme", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-workers", type=int, default=0,
+                    help="also time the CPU baseline with this many member processes (ensemble runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -221,6 +242,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, N, scheme)
             out["cpu_baseline_fair"] = cpu_baseline(args.config, N, scheme, fair=True)
+            if args.cpu_workers > 1:
+                out["cpu_baseline_members"] = cpu_baseline(args.config, N, scheme, workers=args.cpu_workers)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
