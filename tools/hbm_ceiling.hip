@@ -126,6 +126,26 @@ int main() {
         snprintf(nm, 64, "chunk_walk r22 w3, %d threads x %d rows", stride, rows);
         report(nm, 25.0 * n * 8, ms);
     }
+    {   // the same walks over four alternating input sets (1.3 GB): nothing is left in the
+        // 256 MB on-die cache from the previous pass, as in a time step
+        double* big;
+        CK(hipMalloc(&big, 4 * 40 * n * 8)); CK(hipMemset(big, 0, 4 * 40 * n * 8)); CK(hipDeviceSynchronize());
+        int turn = 0;
+        for (int rows : {32}) {
+            const int stride = (int)(n / rows);
+            const int g2 = (stride + 63) / 64;
+            ms = time_ms([&] { chunk_walk<39, 3><<<g2, 64>>>(big + (long)(turn++ % 4) * 40 * n, out, n, stride, rows); }, 32);
+            report("chunk_walk r39 w3, cold inputs (4 sets)", 42.0 * n * 8, ms);
+            ms = time_ms([&] { chunk_walk<22, 3><<<g2, 64>>>(big + (long)(turn++ % 4) * 40 * n, out, n, stride, rows); }, 32);
+            report("chunk_walk r22 w3, cold inputs (4 sets)", 25.0 * n * 8, ms);
+        }
+        const int blk2 = 256; const int gridp = (int)((n + blk2 - 1) / blk2);
+        ms = time_ms([&] { planes<25, 1><<<gridp, blk2>>>(big + (long)(turn++ % 4) * 40 * n, out, n); }, 32);
+        report("planes r25 w1, cold inputs (4 sets)", 26.0 * n * 8, ms);
+        ms = time_ms([&] { planes<3, 25><<<gridp, blk2>>>(big + (long)(turn++ % 4) * 40 * n, big + (long)((turn + 1) % 4) * 40 * n, n); }, 32);
+        report("planes r3 w25, rotating outputs (4 sets)", 28.0 * n * 8, ms);
+        CK(hipFree(big));
+    }
     const long n2 = 25 * n / 2;
     for (int g : {2048, 8192, 32768}) {
         ms = time_ms([&] { fill2<<<g, blk>>>((double2*)out, n2); });
