@@ -60,9 +60,7 @@ typedef struct tf_solver_opts {
     int32_t berr_every;   /* refine = -1: after the first factorisations (and whenever c
                              moves by > 10 %) the backward error is re-measured on every
                              berr_every-th factorisation (0 = default 8, 1 = always)  */
-    int32_t tail_chunks;  /* reduced levels with at most this many chunks run fused in
-                             one single-workgroup launch (0 = off, the default: measured
-                             no faster than separate launches on MI355X)            */
+    int32_t reserved;     /* must be 0 */
 } tf_solver_opts;
 
 const char* tf_last_error(void);

@@ -109,8 +109,6 @@ void launch(Module*, int kernel, unsigned gx, unsigned gy, unsigned block,
         for (int64_t t = 0; t < nthreads; ++t) tfk_top_body<TF_B2, true>(a, (int)t); } break;
     case TFK_TOP_SOLVE: { const auto& a = *(const TfTopArgs*)args;
         for (int64_t t = 0; t < nthreads; ++t) tfk_top_body<TF_B2, false>(a, (int)t); } break;
-    case TFK_TAIL: { const auto& a = *(const TfTailArgs*)args;
-        tfk_tail_body<TF_B2>(a, 0, 1, [] {}); } break;
     default: throw std::runtime_error("emu: unknown kernel");
     }
 }

@@ -50,6 +50,15 @@ def test_linear_solve_small(name):
     pc.check_linear_solve(name, HIP, 203, plans, tol=tol)
 
 
+@pytest.mark.parametrize("name", ["M3_film", "M5_stiff", "wide4", "six", "bivar"])
+def test_factorisation_is_accurate_without_refinement(name):
+    """The automatic refinement must not be what makes a solve right: with it switched
+    off the factorisation alone agrees with SuperLU (this is what catches a miscompiled
+    solver kernel, DESIGN.md "compiler notes")."""
+    pc.check_linear_solve(name, HIP, 203, [dict(refine=0), dict(refine=0, m1=8, m_upper=4)],
+                          tol=1e-7 if name == "wide4" else 1e-9)
+
+
 @pytest.mark.parametrize("name", ["M2_diff", "M3_film", "M5_stiff", "wide4", "six"])
 def test_linear_solve_medium(name):
     pc.check_linear_solve(name, HIP, 20011, [dict(), dict(m1=16, m_upper=4)],

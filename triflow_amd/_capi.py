@@ -24,7 +24,7 @@ class ModelSpec(C.Structure):
 class SolverOpts(C.Structure):
     _fields_ = [("m1", C.c_int32), ("m_upper", C.c_int32), ("nstate", C.c_int32),
                 ("refine", C.c_int32), ("device", C.c_int32), ("berr_every", C.c_int32),
-                ("tail_chunks", C.c_int32)]
+                ("reserved", C.c_int32)]
 
 
 #: name -> (restype, argtypes); every symbol declared in include/triflow_hip.h
@@ -150,7 +150,7 @@ class DeviceSolver:
     """``tf_solver``: resident state + kernels for ``nsys`` systems of ``N`` nodes."""
 
     def __init__(self, model, N, nsys=1, periodic=False, m1=0, m_upper=0, nstate=0,
-                 refine=-1, device=-1, tail_chunks=0, berr_every=0):
+                 refine=-1, device=-1, berr_every=0):
         self.model = model
         self.lib = model.lib
         self.N, self.nsys, self.periodic = int(N), int(nsys), bool(periodic)
@@ -158,8 +158,7 @@ class DeviceSolver:
         self.npar, self.nnz = model.spec["npar"], model.spec["nnz"]
         m1 = m1 or int(os.environ.get("TRIFLOW_M1", "0"))
         m_upper = m_upper or int(os.environ.get("TRIFLOW_M_UPPER", "0"))
-        tail_chunks = tail_chunks or int(os.environ.get("TRIFLOW_TAIL_CHUNKS", "0"))
-        opts = SolverOpts(m1, m_upper, nstate, refine, device, berr_every, tail_chunks)
+        opts = SolverOpts(m1, m_upper, nstate, refine, device, berr_every, 0)
         handle = C.c_void_p()
         self.lib.call("tf_solver_create", model.handle, self.N, self.nsys,
                       int(self.periodic), C.byref(opts), C.byref(handle))

@@ -166,28 +166,18 @@ struct TfTopArgs {                 // final 1-node system per ensemble member
 // nodes per chunk of a cyclic-reduction level (one wavefront: 8 nodes x 8 lanes per round)
 #define TF_CR_MAXLEN 16
 
-// The smallest reduced levels and the top block run as phases of ONE single-
-// workgroup launch (no launch gaps between their latency-bound kernels).
-#define TF_MAX_TAIL 8
-struct TfTailArgs {
-    int nlv;                       // levels fused (ordered fine -> coarse)
-    int factor;                    // 1: factor phase, 0: solve phase
-    TfLevelArgs lv[TF_MAX_TAIL];
-    TfTopArgs top;
-};
-
 // Kernel table: index = launch id used by the runtime, name = entry point in
 // the per-model code object (tf_entry_hip.h).
 enum TfKernel {
     TFK_SWEEP_F = 0, TFK_SWEEP_FJ, TFK_SPMV, TFK_VEC, TFK_VEC_MAXABS, TFK_PERM, TFK_DIRICHLET,
     TFK_L1_FACTOR, TFK_L1_SOLVE, TFK_L1_ASM_MAT, TFK_L1_ASM_RHS, TFK_L1_BACKSUB,
     TFK_BT_LU, TFK_BT_SPIKE, TFK_BT_RHS, TFK_BT_ASM_MAT, TFK_BT_ASM_RHS, TFK_BT_BACKSUB,
-    TFK_TOP_FACTOR, TFK_TOP_SOLVE, TFK_BERR, TFK_TAIL, TFK_DIFFNORM, TFK_L1_FACTOR_RHS, TFK_SWEEP_F_STAGE,
+    TFK_TOP_FACTOR, TFK_TOP_SOLVE, TFK_BERR, TFK_DIFFNORM, TFK_L1_FACTOR_RHS, TFK_SWEEP_F_STAGE,
     TFK_CR_FACTOR, TFK_CR_FWD, TFK_CR_BWD, TFK_COUNT
 };
 #define TF_KERNEL_NAMES { \
     "tfk_sweep_f", "tfk_sweep_fj", "tfk_spmv", "tfk_vec", "tfk_vec_maxabs", "tfk_perm", "tfk_dirichlet", \
     "tfk_l1_factor", "tfk_l1_solve", "tfk_l1_asm_mat", "tfk_l1_asm_rhs", "tfk_l1_backsub", \
     "tfk_bt_lu", "tfk_bt_spike", "tfk_bt_rhs", "tfk_bt_asm_mat", "tfk_bt_asm_rhs", "tfk_bt_backsub", \
-    "tfk_top_factor", "tfk_top_solve", "tfk_berr", "tfk_tail", "tfk_diffnorm", "tfk_l1_factor_rhs", "tfk_sweep_f_stage", \
+    "tfk_top_factor", "tfk_top_solve", "tfk_berr", "tfk_diffnorm", "tfk_l1_factor_rhs", "tfk_sweep_f_stage", \
     "tfk_cr_factor", "tfk_cr_fwd", "tfk_cr_bwd" }

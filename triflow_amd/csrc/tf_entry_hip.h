@@ -167,10 +167,4 @@ __global__ void __launch_bounds__(64) tfk_cr_bwd(TfLevelArgs a) {
     if constexpr (TF_B2 >= 3 && TF_B2 <= 8) tfk_cr_bwd_coop<TF_B2>(a);
 }
 
-// one workgroup of 256 threads; phases separated by workgroup barriers (the data
-// handed from phase to phase stays on this CU: same L1, L2 write-through)
-__global__ void __launch_bounds__(256) tfk_tail(TfTailArgs a) {
-    tfk_tail_body<TF_B2>(a, threadIdx.x, blockDim.x, [] { __threadfence_block(); __syncthreads(); });
-}
-
 }  // extern "C"

@@ -1148,8 +1148,8 @@ TF_DEVICE void tfk_backsub_body(const TfLevelArgs& a, int pg) {
 #pragma unroll
         for (int r = 0; r < B; ++r) a.x[(int64_t)r * L.plane + s] = xn[t][r];
     }
-    // the factors of nodes j-1..j-3 are requested before node j is processed: one
-    // HBM latency is paid per chunk, not per node, with three nodes in flight
+    // the factors of node j-1 are requested before node j is processed, so one
+    // HBM latency is paid per chunk, not per node
     struct Node { double y[B]; double U[UW][B][B]; double E[MP][B][B]; };
     auto load = [&](int j, Node& n) {
         const int64_t s = tf_idx(L, pg, j);
@@ -1165,11 +1165,10 @@ TF_DEVICE void tfk_backsub_body(const TfLevelArgs& a, int pg) {
                     if (c < MP) n.E[c < MP ? c : 0][r][k] = a.Et[(int64_t)((c * B + r) * B + k) * L.plane + s];
                 }
     };
-    Node cur = {}, nx1 = {}, nx2 = {};
+    Node cur = {}, nxt = {};
     load(mI - 1, cur);
-    if (mI > 1) load(mI - 2, nx1);
-    if (mI > 2) load(mI - 3, nx2);
     for (int j = mI - 1; j >= 0; --j) {
+        if (j > 0) load(j - 1, nxt);
         const int64_t s = tf_idx(L, pg, j);
         double x[B];
 #pragma unroll
@@ -1178,15 +1177,13 @@ TF_DEVICE void tfk_backsub_body(const TfLevelArgs& a, int pg) {
         for (int c = 0; c < UW; ++c) tf_mv_sub<B>(x, cur.U[c], xn[c]);
 #pragma unroll
         for (int c = 0; c < MP; ++c) tf_mv_sub<B>(x, cur.E[c], sa[c]);
-        cur = nx1;
-        nx1 = nx2;
-        if (j > 2) load(j - 3, nx2);
 #pragma unroll
         for (int c = UW - 1; c > 0; --c)
 #pragma unroll
             for (int r = 0; r < B; ++r) xn[c][r] = xn[c - 1][r];
 #pragma unroll
         for (int r = 0; r < B; ++r) { xn[0][r] = x[r]; a.x[(int64_t)r * L.plane + s] = x[r]; }
+        cur = nxt;
     }
 }
 
@@ -1225,45 +1222,5 @@ TF_DEVICE void tfk_top_body(const TfTopArgs& a, int e) {
         tf_mv<BB>(x, Di, g);
 #pragma unroll
         for (int r = 0; r < BB; ++r) a.x[a.aos ? (int64_t)e * BB + r : (int64_t)r * a.nsys + e] = x[r];
-    }
-}
-
-// ---- fused tail: all phases of the smallest levels + top in one workgroup -----
-// `sync()` separates phases (workgroup barrier on the device, nothing in the
-// single-threaded host build); thread `tid` of `nthreads` strides over the work
-// items of each phase.
-template <int BB, class Sync>
-TF_DEVICE void tfk_tail_body(const TfTailArgs& a, int tid, int nthreads, Sync sync) {
-    typedef TfRowsBT<BB> Rows;
-    for (int l = 0; l < a.nlv; ++l) {
-        const TfLevelArgs& lv = a.lv[l];
-        const int np = lv.L.Ptot;
-        if (a.factor) {
-            for (int t = tid; t < 2 * np; t += nthreads) tfk_bt_lu_body<BB>(lv, t % np, t < np ? +1 : -1);
-            sync();
-            for (int t = tid; t < 2 * BB * np; t += nthreads) {
-                const int y = t / np;
-                tfk_bt_col_body<BB>(lv, t % np, (y & 1) == 0 ? +1 : -1, y >> 1);
-            }
-            sync();
-            for (int t = tid; t < np; t += nthreads) tfk_asm_body<Rows, true>(lv, t);
-            sync();
-        } else {
-            for (int t = tid; t < 2 * np; t += nthreads) tfk_bt_col_body<BB>(lv, t % np, t < np ? +1 : -1, BB);
-            sync();
-            for (int t = tid; t < np; t += nthreads) tfk_asm_body<Rows, false>(lv, t);
-            sync();
-        }
-    }
-    if (a.factor) {
-        for (int t = tid; t < a.top.nsys; t += nthreads) tfk_top_body<BB, true>(a.top, t);
-    } else {
-        for (int t = tid; t < a.top.nsys; t += nthreads) tfk_top_body<BB, false>(a.top, t);
-        sync();
-        for (int l = a.nlv - 1; l >= 0; --l) {
-            const TfLevelArgs& lv = a.lv[l];
-            for (int t = tid; t < lv.L.Ptot; t += nthreads) tfk_backsub_body<Rows>(lv, t);
-            sync();
-        }
     }
 }

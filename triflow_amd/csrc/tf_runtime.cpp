@@ -295,25 +295,11 @@ struct tf_solver {
         a.next_aos = next_aos(l) ? 1 : 0; a.crf = lv.crf.p; a.zt = lv.zt.p;
         return a;
     }
-    // first level handled by the fused single-workgroup tail (levels.size() = none)
-    size_t tail_from = 0;
     TfTopArgs top_args() {
         TfTopArgs t;
         t.nsys = nsys; t.A = top.Ablk.p; t.rhs = top.rhs.p; t.Ainv = topAinv.p; t.x = top.x.p; t.status = status;
         t.aos = levels.back()->cr ? 1 : 0;
         return t;
-    }
-    void launch_tail(bool is_factor, const double* rhs1, double* x1) {
-        TfTailArgs a;
-        std::memset(&a, 0, sizeof(a));
-        a.nlv = (int)(levels.size() - tail_from);
-        a.factor = is_factor ? 1 : 0;
-        for (size_t l = tail_from; l < levels.size(); ++l) {
-            a.lv[l - tail_from] = level_args(l, rhs1, x1);
-            if (is_factor) a.lv[l - tail_from].rhs = nullptr;
-        }
-        a.top = top_args();
-        launch(TFK_TAIL, 1, 1, 256, &a, sizeof(a));
     }
     // Factorise I - c J.  With `rhs1` the first right-hand side is eliminated in the
     // same walks (level 1: the factor kernel carries it next to the spike columns;
@@ -323,8 +309,8 @@ struct tf_solver {
     void factor(double c, const double* rhs1 = nullptr, double* x1 = nullptr) {
         if (!have_jac) throw std::runtime_error("tf_factor: no Jacobian evaluated yet (call tf_eval with_j=1)");
         factor_c = c;
-        const bool fused = rhs1 != nullptr && tail_from >= levels.size();
-        for (size_t l = 0; l < tail_from; ++l) {
+        const bool fused = rhs1 != nullptr;
+        for (size_t l = 0; l < levels.size(); ++l) {
             TfLevelArgs a = level_args(l, rhs1, x1);
             if (!fused) a.rhs = nullptr;
             unsigned gx = cdiv(a.L.Ptot, 64);
@@ -345,8 +331,7 @@ struct tf_solver {
             if (l == 0) launch(TFK_L1_ASM_MAT, gx, 1, 64, &a, sizeof(a));
             else launch(TFK_BT_ASM_MAT, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
         }
-        if (tail_from < levels.size()) launch_tail(true, nullptr, nullptr);
-        else { TfTopArgs t = top_args(); launch(TFK_TOP_FACTOR, cdiv((int64_t)nsys * (tfb::coop_group(top.B) == 8 ? 8 : 1), 64), 1, 64, &t, sizeof(t)); }
+        { TfTopArgs t = top_args(); launch(TFK_TOP_FACTOR, cdiv((int64_t)nsys * (tfb::coop_group(top.B) == 8 ? 8 : 1), 64), 1, 64, &t, sizeof(t)); }
         have_factor = true;
         ++n_factor;
         const bool c_moved = std::fabs(c - checked_c) > 0.1 * std::fabs(checked_c);
@@ -361,7 +346,7 @@ struct tf_solver {
         polish(rhs1, x1);
     }
     void backsub_chain(const double* rhs1, double* x1) {
-        for (size_t l = tail_from; l-- > 0;) {
+        for (size_t l = levels.size(); l-- > 0;) {
             TfLevelArgs a = level_args(l, rhs1, x1);
             if (l == 0) launch(TFK_L1_BACKSUB, cdiv(a.L.Ptot, 64), 1, 64, &a, sizeof(a));
             else if (levels[l]->cr) launch(TFK_CR_BWD, (unsigned)a.L.Ptot, 1, 64, &a, sizeof(a));
@@ -369,7 +354,7 @@ struct tf_solver {
         }
     }
     void solve_once(const double* rhs1, double* x1) {
-        for (size_t l = 0; l < tail_from; ++l) {
+        for (size_t l = 0; l < levels.size(); ++l) {
             TfLevelArgs a = level_args(l, rhs1, x1);
             unsigned gx = cdiv(a.L.Ptot, 64);
             if (l == 0) launch(TFK_L1_SOLVE, gx, 2, 64, &a, sizeof(a));
@@ -378,8 +363,7 @@ struct tf_solver {
             if (l == 0) launch(TFK_L1_ASM_RHS, gx, 1, 64, &a, sizeof(a));
             else launch(TFK_BT_ASM_RHS, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
         }
-        if (tail_from < levels.size()) launch_tail(false, rhs1, x1);
-        else { TfTopArgs t = top_args(); launch(TFK_TOP_SOLVE, cdiv(nsys, 64), 1, 64, &t, sizeof(t)); }
+        { TfTopArgs t = top_args(); launch(TFK_TOP_SOLVE, cdiv(nsys, 64), 1, 64, &t, sizeof(t)); }
         backsub_chain(rhs1, x1);
     }
     void refine_sweep(const double* rhs1, double* x1) {
@@ -548,13 +532,6 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
         }
         s->top.L = make_layout(nsys, 1, 1, s->periodic);
         s->top.B = b2; s->top.MP = 1;
-    }
-    {
-        const bool any_cr = s->levels.back()->cr;
-        const int tail_chunks = opts && opts->tail_chunks > 0 && !any_cr ? opts->tail_chunks : 0;
-        s->tail_from = s->levels.size();
-        for (size_t l = 1; l < s->levels.size(); ++l)
-            if (s->levels[l]->L.Ptot <= tail_chunks && s->levels.size() - l <= TF_MAX_TAIL) { s->tail_from = l; break; }
     }
     s->L1 = s->levels[0]->L;
     const int64_t plane = s->L1.plane;
