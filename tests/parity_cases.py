@@ -468,7 +468,7 @@ def check_unstable_factorisation_is_loud(backend):
     assert refined and omega < 1e-10
 
 
-def check_ensemble_equals_single_members(backend, N=3000, nsys=3, steps=3, **opts):
+def check_ensemble_equals_single_members(backend, N=3000, nsys=3, steps=3, exact=True, **opts):
     """nsys members stepped together in one solver (per-member scalar parameters and
     initial conditions) give, member by member, the bits of nsys separate single-member
     solvers: the batch dimension only adds chunks to the same kernels."""
@@ -490,7 +490,11 @@ def check_ensemble_equals_single_members(backend, N=3000, nsys=3, steps=3, **opt
         for _ in range(steps):
             one.step(dt)
         one.sync()
-        assert np.array_equal(one.state()[:, 0, :], batch[:, e, :]), e
+        if exact:        # same level plan for the batch and the single member: same bits
+            assert np.array_equal(one.state()[:, 0, :], batch[:, e, :]), e
+        else:            # plans chosen from the total size differ: same solution to solver accuracy
+            ref = one.state()[:, 0, :]
+            assert np.abs(ref - batch[:, e, :]).max() <= 1e-10 * np.abs(ref).max(), e
     # and the members differ from each other
     assert not np.array_equal(batch[:, 0, :], batch[:, 1, :])
     # member 1 against the scheme API on the same inputs (its solver may use another level

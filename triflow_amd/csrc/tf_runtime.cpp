@@ -494,13 +494,12 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
     require(N * (int64_t)nsys < (int64_t)1 << 31, "tf_solver_create: too many nodes for 32-bit chunk indices");
     std::unique_ptr<tf_solver> s(new tf_solver());
     s->model = model; s->spec = sp; s->N = N; s->nsys = nsys; s->periodic = periodic ? 1 : 0;
-    int m1 = opts && opts->m1 > 0 ? opts->m1 : 32;
+    int m1 = opts && opts->m1 > 0 ? opts->m1 : 0;             // 0: chosen below from the problem size
     int mup = opts && opts->m_upper > 0 ? opts->m_upper : 6;
     s->nstate = opts && opts->nstate > 0 ? opts->nstate : 3;
     s->refine = opts ? opts->refine : -1;      // 0 = never, n > 0 = fixed sweeps, -1 = auto
     if (opts && opts->berr_every > 0) s->berr_every = opts->berr_every;
     if (opts && opts->device >= 0) tfb::set_device(opts->device);
-    m1 = std::max(m1, 2 * sp.mp);
     mup = std::max(mup, 2);
     s->stream = tfb::stream_create();
 
@@ -509,6 +508,17 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
     // them (3 <= b <= 8 on the GPU) -- cyclic reduction inside chunks of up to 16 nodes.
     const int b2 = sp.mp * sp.nvar;
     s->use_cr = tfb::cyclic_reduction(b2);
+    if (m1 == 0) {
+        // Level-1 chunk length.  A walk costs ~4 us per node of a chunk whatever the grid
+        // size, so a small problem (too few chunks to fill the GPU anyway) is latency-bound
+        // by it: shorter chunks, more (cheap, cyclic-reduction) levels.  Large problems are
+        // throughput-bound and want the smallest reduced system.  Scanned on MI355X with
+        // tools/gpu_small_n_scan.py (N = 200 ... 4e5) and tools/gpu_plan_scan.sh (N = 1e6).
+        const int64_t total = (int64_t)N * nsys;
+        m1 = 32;
+        if (s->use_cr) m1 = total <= 30000 ? 4 : (total <= 200000 ? 8 : (total <= 600000 ? 16 : 32));
+    }
+    m1 = std::max(m1, 2 * sp.mp);
     {
         // Cyclic reduction pays where a level is latency-bound (few chunks): one wavefront
         // per 16-node chunk does about twice the arithmetic of the walks (later rounds leave
