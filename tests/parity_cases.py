@@ -506,3 +506,28 @@ def check_ensemble_equals_single_members(backend, N=3000, nsys=3, steps=3, exact
         t, f = sch(t, f, dt, dict(pars, c=float(c[1]), We=float(We[1])))
     ref = f.uflat.reshape(N, 3).T
     assert np.abs(ref - batch[:, 1, :]).max() <= 1e-9 * np.abs(ref).max()
+
+
+def drift_against_oracle(backend, cfg, N, sch, nsteps=100, marks=(1, 10, 100)):
+    """Relative max-norm difference between the device path and the oracle after the given
+    numbers of steps ("100-step drift reported")."""
+    if cfg == 1:
+        name = "M1_advdiff"
+        x = np.linspace(0, 1, N)
+        fd, pars, dt = {"x": x, "U": np.cos(2 * np.pi * x * 5)}, dict(c=.03, k=.001, periodic=False), 0.5
+        kw_d, kw_o = dict(hook=DEVICE_HOOKS["cfg1"]), dict(hook=corpus.dirichlet_hook_cfg1)
+    else:
+        name, fd, pars, dt, _ = corpus.config_inputs(cfg, N)
+        kw_d = dict(hook=DEVICE_HOOKS["cfg5"]) if cfg == 5 else {}
+        kw_o = dict(hook=corpus.dirichlet_hook_cfg5) if cfg == 5 else {}
+    m, mo = device_model(name, backend), oracle_model(name)
+    pick = lambda mod, mm: {"Theta": mod.Theta, "ROS2": mod.ROS2, "BDF2": mod.BDF2,
+                            "RODASPR": lambda q: mod.RODASPR(q, time_stepping=False)}[sch](mm)
+    dev, ref = pick(schemes, m), pick(ora, mo)
+    f_d, f_o, t, out = m.fields_template(**fd), mo.fields_template(**fd), 0.0, {}
+    for k in range(1, nsteps + 1):
+        _, f_d = dev(t, f_d, dt, pars, **kw_d)
+        t, f_o = ref(t, f_o, dt, pars, **kw_o)
+        if k in marks:
+            out[k] = np.abs(f_d.uflat - f_o.uflat).max() / np.abs(f_o.uflat).max()
+    return out

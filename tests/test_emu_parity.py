@@ -94,3 +94,8 @@ def test_unstable_factorisation_is_loud(backend):
 
 def test_ensemble_equals_single_members(backend):
     pc.check_ensemble_equals_single_members(backend, N=300, m1=8, m_upper=3)
+
+
+def test_twenty_step_drift(backend):
+    d = pc.drift_against_oracle(backend, 3, 400, "ROS2", nsteps=20, marks=(1, 20))
+    assert d[1] <= 1e-11 and d[20] <= 1e-10, d

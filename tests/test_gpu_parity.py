@@ -235,3 +235,12 @@ def test_ensemble_equals_single_members():
     # default plans: chunk length and reduced-level kernels follow the total size of the batch
     pc.check_ensemble_equals_single_members(HIP, N=30000, exact=False)
     pc.check_ensemble_equals_single_members(HIP, N=3000, nsys=2, m1=8, m_upper=3)
+
+
+@pytest.mark.parametrize("cfg,N,sch", [(1, 200, "Theta"), (2, 20000, "Theta"), (3, 20000, "ROS2"),
+                                       (3, 20000, "RODASPR"), (5, 20000, "BDF2")])
+def test_hundred_step_drift(cfg, N, sch):
+    """Measured on MI355X: 1e-14 ... 2e-11 after 100 steps (tools/gpu_drift.py prints the table)."""
+    d = pc.drift_against_oracle(HIP, cfg, N, sch)
+    print("config %d N=%d %s: %.1e / %.1e / %.1e after 1 / 10 / 100 steps" % (cfg, N, sch, d[1], d[10], d[100]))
+    assert d[1] <= 1e-11 and d[100] <= 1e-9, d
