@@ -50,12 +50,14 @@ typedef struct tf_model_spec {
 } tf_model_spec;
 
 typedef struct tf_solver_opts {
-    int32_t m1;           /* chunk length of the first solver level (0 = default)   */
-    int32_t m_upper;      /* chunk length of the reduced levels     (0 = default)   */
+    int32_t m1;           /* chunk length of the first solver level (0 = by problem
+                             size: 4 ... 32 nodes)                                  */
+    int32_t m_upper;      /* chunk length of the reduced levels (0 = default: 6 for
+                             the chunk walks, 16 = the maximum for cyclic reduction) */
     int32_t nstate;       /* resident state slots                   (0 = default 3) */
     int32_t refine;       /* refinement sweeps per solve; 0 = none, -1 = automatic:
                              measure the backward error of the first solve after
-                             each factorisation and polish only if it is > 1e-10   */
+                             each factorisation and polish only if it is > 1e-11   */
     int32_t device;       /* HIP device ordinal (-1 = current)                      */
     int32_t berr_every;   /* refine = -1: after the first factorisations (and whenever c
                              moves by > 10 %) the backward error is re-measured on every
