@@ -151,6 +151,11 @@ struct TfLevelArgs {
     int cr_rhs;                    // tfk_cr_factor: also eliminate the right-hand side
     double* crf;                   // [node][5][b][b]: Dinv, E, F, Ua, Lb of the eliminated node
     double* zt;                    // [node][b]: Dinv * y of the eliminated node
+    // last cyclic-reduction level (one chunk per system): it also inverts / applies the
+    // single block that is left (what tfk_top_* do otherwise)
+    int fold_top;
+    double* topAinv;               // [b][b] planes over systems (TfTopArgs::Ainv)
+    double* topx;                  // [sys][b]
 };
 
 struct TfTopArgs {                 // final 1-node system per ensemble member

@@ -661,6 +661,28 @@ __device__ __forceinline__ void tfk_cr_factor_coop(const TfLevelArgs& a) {
             if (with_rhs) rr[BB + g] = sY[0][g];
         }
     }
+    if (a.fold_top) {
+        // one chunk per system: what is left of rows 0 and pe couples the separator to
+        // itself only (TfTopArgs): invert their sum here, and solve for the first rhs
+        __syncthreads();
+        const bool on = grp == 0 && row_on;
+        double S[BB], INV[BB];
+#pragma unroll
+        for (int c = 0; c < BB; ++c)
+            S[c] = rL(pe)[gq * BB + c] + rD(pe)[gq * BB + c] + rU(0)[gq * BB + c] + rD(0)[gq * BB + c];
+        const int myk = tf_gj_coop<BB, G>(S, INV, on, g, sX + grp * 2 * G * (2 * BB + 1), ok);
+        if (on) {
+            const int nsys = L.Ptot;                 // P == 1
+#pragma unroll
+            for (int c = 0; c < BB; ++c) a.topAinv[(int64_t)(myk * BB + c) * nsys + ch.e] = INV[c];
+            if (with_rhs) {
+                double x = 0.0;
+#pragma unroll
+                for (int c = 0; c < BB; ++c) x = tf_fma(INV[c], sY[pe][c] + sY[0][c], x);
+                a.topx[(int64_t)ch.e * BB + myk] = x;
+            }
+        }
+    }
     if (!ok) *a.status = 1;
 }
 
@@ -744,7 +766,17 @@ __device__ __forceinline__ void tfk_cr_fwd_coop(const TfLevelArgs& a) {
             __syncthreads();
         }
     }
-    if (row_on && grp < 2) {
+    if (a.fold_top) {
+        // last level: apply the inverse of the remaining block (tfk_cr_factor_coop)
+        if (row_on && grp == 0) {
+            const int nsys = L.Ptot;
+            double x = 0.0;
+#pragma unroll
+            for (int c = 0; c < BB; ++c)
+                x = tf_fma(a.topAinv[(int64_t)(g * BB + c) * nsys + ch.e], sY[pe][c] + sY[0][c], x);
+            a.topx[(int64_t)ch.e * BB + g] = x;
+        }
+    } else if (row_on && grp < 2) {
         const int nn = grp == 0 ? ch.p : ch.pprev;
         double* rr = a.rhsnext + ((int64_t)ch.e * a.Lnext.N + nn) * 2 * BB;
         if (grp == 0) rr[g] = sY[pe][g]; else rr[BB + g] = sY[0][g];

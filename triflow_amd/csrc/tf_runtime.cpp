@@ -95,6 +95,8 @@ struct tf_solver {
     bool use_cr = false;   // the back end has the cyclic-reduction kernels (tfk_cr_*) for this block size
     // storage of what a level hands to the next one: records per node (below a cyclic-
     // reduction level) or partition-interleaved planes
+    // the last level is a cyclic-reduction level: it handles the top block itself
+    bool fold_top() const { return levels.size() > 1 && levels.back()->cr; }
     bool level_cr(size_t l) const { return l < levels.size() && levels[l]->cr; }
     bool next_aos(size_t l) const { return l + 1 < levels.size() ? levels[l + 1]->cr : levels.back()->cr; }
     tfb::Stream* stream = nullptr;
@@ -293,6 +295,8 @@ struct tf_solver {
         a.Lnext = nx.L; a.Anext = nx.Ablk.p; a.rhsnext = nx.rhs.p; a.xnext = nx.x.p;
         a.status = status;
         a.next_aos = next_aos(l) ? 1 : 0; a.crf = lv.crf.p; a.zt = lv.zt.p;
+        a.fold_top = fold_top() && l + 1 == levels.size() ? 1 : 0;
+        a.topAinv = topAinv.p; a.topx = top.x.p;
         return a;
     }
     TfTopArgs top_args() {
@@ -331,7 +335,7 @@ struct tf_solver {
             if (l == 0) launch(TFK_L1_ASM_MAT, gx, 1, 64, &a, sizeof(a));
             else launch(TFK_BT_ASM_MAT, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
         }
-        { TfTopArgs t = top_args(); launch(TFK_TOP_FACTOR, cdiv((int64_t)nsys * (tfb::coop_group(top.B) == 8 ? 8 : 1), 64), 1, 64, &t, sizeof(t)); }
+        if (!fold_top()) { TfTopArgs t = top_args(); launch(TFK_TOP_FACTOR, cdiv((int64_t)nsys * (tfb::coop_group(top.B) == 8 ? 8 : 1), 64), 1, 64, &t, sizeof(t)); }
         have_factor = true;
         ++n_factor;
         const bool c_moved = std::fabs(c - checked_c) > 0.1 * std::fabs(checked_c);
@@ -340,8 +344,7 @@ struct tf_solver {
         // (between checks the verdict of the last checked factorisation stands)
         if (rhs1 == nullptr) return;
         if (!fused) { solve(rhs1, x1); return; }
-        TfTopArgs t = top_args();
-        launch(TFK_TOP_SOLVE, cdiv(nsys, 64), 1, 64, &t, sizeof(t));
+        if (!fold_top()) { TfTopArgs t = top_args(); launch(TFK_TOP_SOLVE, cdiv(nsys, 64), 1, 64, &t, sizeof(t)); }
         backsub_chain(rhs1, x1);
         polish(rhs1, x1);
     }
@@ -363,7 +366,7 @@ struct tf_solver {
             if (l == 0) launch(TFK_L1_ASM_RHS, gx, 1, 64, &a, sizeof(a));
             else launch(TFK_BT_ASM_RHS, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
         }
-        { TfTopArgs t = top_args(); launch(TFK_TOP_SOLVE, cdiv(nsys, 64), 1, 64, &t, sizeof(t)); }
+        if (!fold_top()) { TfTopArgs t = top_args(); launch(TFK_TOP_SOLVE, cdiv(nsys, 64), 1, 64, &t, sizeof(t)); }
         backsub_chain(rhs1, x1);
     }
     void refine_sweep(const double* rhs1, double* x1) {
