@@ -675,11 +675,40 @@ __device__ __forceinline__ void tfk_cr_factor_coop(const TfLevelArgs& a) {
             const int nsys = L.Ptot;                 // P == 1
 #pragma unroll
             for (int c = 0; c < BB; ++c) a.topAinv[(int64_t)(myk * BB + c) * nsys + ch.e] = INV[c];
-            if (with_rhs) {
-                double x = 0.0;
+        }
+        if (with_rhs) {
+            // ... and the back-substitution of this level (tfk_cr_bwd_coop): E_k, F_k and z_k
+            // are still in LDS; sY takes the solution
+            double x = 0.0;
+            if (on) {
 #pragma unroll
                 for (int c = 0; c < BB; ++c) x = tf_fma(INV[c], sY[pe][c] + sY[0][c], x);
+            }
+            __syncthreads();
+            if (on) {
                 a.topx[(int64_t)ch.e * BB + myk] = x;
+                a.x[(ch.nbase + ch.node(pe)) * BB + myk] = x;
+                sY[pe][myk] = x;
+                sY[0][myk] = ch.has_prev ? x : 0.0;
+            }
+            __syncthreads();
+            int s = 1;
+            while (2 * s <= mI) s <<= 1;
+            for (; s >= 1; s >>= 1) {
+                const int nA = (mI / s + 1) / 2;
+                if (grp < nA && row_on) {
+                    const int k = s * (2 * grp + 1);
+                    const int kl = k - s, kr = k + s <= mI ? k + s : pe;
+                    double xk = sZ[k][g];
+#pragma unroll
+                    for (int m = 0; m < BB; ++m) {
+                        xk = tf_fma(-rL(k)[g * BB + m], sY[kl][m], xk);
+                        xk = tf_fma(-rU(k)[g * BB + m], sY[kr][m], xk);
+                    }
+                    sY[k][g] = xk;
+                    a.x[(ch.nbase + ch.node(k)) * BB + g] = xk;
+                }
+                __syncthreads();
             }
         }
     }
@@ -767,14 +796,43 @@ __device__ __forceinline__ void tfk_cr_fwd_coop(const TfLevelArgs& a) {
         }
     }
     if (a.fold_top) {
-        // last level: apply the inverse of the remaining block (tfk_cr_factor_coop)
+        // last level: apply the inverse of the remaining block (tfk_cr_factor_coop) and run
+        // the back-substitution rounds of this level right away (tfk_cr_bwd_coop)
+        double x = 0.0;
         if (row_on && grp == 0) {
             const int nsys = L.Ptot;
-            double x = 0.0;
 #pragma unroll
             for (int c = 0; c < BB; ++c)
                 x = tf_fma(a.topAinv[(int64_t)(g * BB + c) * nsys + ch.e], sY[pe][c] + sY[0][c], x);
+        }
+        __syncthreads();
+        if (row_on && grp == 0) {
             a.topx[(int64_t)ch.e * BB + g] = x;
+            a.x[(ch.nbase + ch.node(pe)) * BB + g] = x;
+            sY[pe][g] = x;
+            sY[0][g] = ch.has_prev ? x : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = MAXR - 1; r >= 0; --r) {
+            const int s = 1 << r;
+            if (s <= mI) {
+                const int nA = (mI / s + 1) / 2;
+                if (grp < nA && row_on) {
+                    const int k = s * (2 * grp + 1);
+                    const int kl = k - s, kr = k + s <= mI ? k + s : pe;
+                    const double* rec = a.crf + (ch.nbase + ch.node(k)) * 5 * B2 + g * BB;
+                    double xk = sZ[k][g];
+#pragma unroll
+                    for (int m = 0; m < BB; ++m) {
+                        xk = tf_fma(-rec[1 * B2 + m], sY[kl][m], xk);
+                        xk = tf_fma(-rec[2 * B2 + m], sY[kr][m], xk);
+                    }
+                    sY[k][g] = xk;
+                    a.x[(ch.nbase + ch.node(k)) * BB + g] = xk;
+                }
+                __syncthreads();
+            }
         }
     } else if (row_on && grp < 2) {
         const int nn = grp == 0 ? ch.p : ch.pprev;

@@ -345,11 +345,13 @@ struct tf_solver {
         if (rhs1 == nullptr) return;
         if (!fused) { solve(rhs1, x1); return; }
         if (!fold_top()) { TfTopArgs t = top_args(); launch(TFK_TOP_SOLVE, cdiv(nsys, 64), 1, 64, &t, sizeof(t)); }
-        backsub_chain(rhs1, x1);
+        backsub_chain(rhs1, x1, fold_top());
         polish(rhs1, x1);
     }
-    void backsub_chain(const double* rhs1, double* x1) {
-        for (size_t l = levels.size(); l-- > 0;) {
+    // skip_last: the last level's back-substitution already ran inside its forward /
+    // factor kernel (cyclic-reduction level that folds the top block in)
+    void backsub_chain(const double* rhs1, double* x1, bool skip_last) {
+        for (size_t l = levels.size() - (skip_last ? 1 : 0); l-- > 0;) {
             TfLevelArgs a = level_args(l, rhs1, x1);
             if (l == 0) launch(TFK_L1_BACKSUB, cdiv(a.L.Ptot, 64), 1, 64, &a, sizeof(a));
             else if (levels[l]->cr) launch(TFK_CR_BWD, (unsigned)a.L.Ptot, 1, 64, &a, sizeof(a));
@@ -367,7 +369,7 @@ struct tf_solver {
             else launch(TFK_BT_ASM_RHS, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
         }
         if (!fold_top()) { TfTopArgs t = top_args(); launch(TFK_TOP_SOLVE, cdiv(nsys, 64), 1, 64, &t, sizeof(t)); }
-        backsub_chain(rhs1, x1);
+        backsub_chain(rhs1, x1, fold_top());
     }
     void refine_sweep(const double* rhs1, double* x1) {
         spmv(x1, Wjv.p, factor_c);                               // c J x
