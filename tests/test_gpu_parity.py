@@ -244,3 +244,16 @@ def test_hundred_step_drift(cfg, N, sch):
     d = pc.drift_against_oracle(HIP, cfg, N, sch)
     print("config %d N=%d %s: %.1e / %.1e / %.1e after 1 / 10 / 100 steps" % (cfg, N, sch, d[1], d[10], d[100]))
     assert d[1] <= 1e-11 and d[100] <= 1e-9, d
+
+
+@pytest.mark.parametrize("script,args", [("advection_diffusion.py", []), ("film_rosenbrock.py", ["20000"]),
+                                          ("parameter_sweep.py", ["20000", "4"])])
+def test_examples_run(script, args):
+    """The scripts under examples/ (the reference README's example among them) run as they are."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "examples", script), *args], cwd=root,
+                         env=dict(os.environ, PYTHONPATH=root), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    if script == "advection_diffusion.py":
+        assert "t: 2.5" in res.stdout and res.stdout.count("iteration") == 5, res.stdout
