@@ -1,5 +1,6 @@
-"""The example of the reference's README, unchanged apart from the import line:
-advection-diffusion of a cosine with Dirichlet values set by a Python hook."""
+"""The example of the reference's README (README.md:104-139; plotting left out,
+``Simulation`` called with the keyword names of ``simulation.py:160-175``), only the import
+line differs: advection-diffusion of a cosine with Dirichlet values set by a Python hook."""
 import numpy as np
 from triflow_amd import Model, Simulation
 
