@@ -103,6 +103,11 @@ int tf_set_dirichlet(tf_solver*, int32_t n, const int32_t* var, const int64_t* n
  * hook(t, ...) at the start of a step, `after` where it calls hook(t + dt, ...)
  * (either may be NULL = unchanged); same entries as the last tf_set_dirichlet */
 int tf_set_dirichlet_values(tf_solver*, const double* before, const double* after);
+/* n point writes state[var[i]][node[i]] = value[i] (negative nodes count from the end) into a
+   resident slot, for every system: what a Python hook like the reference README's
+   ``fields.U[0] = 1`` does, without moving the state over PCIe.                         */
+int tf_poke(tf_solver*, int32_t slot, int32_t n, const int32_t* var, const int64_t* node,
+            const double* value);
 
 /* ---- seam #1: F / J evaluation on the resident state ----------------------- */
 int tf_eval(tf_solver*, int32_t slot, int32_t with_j);

@@ -531,3 +531,41 @@ def drift_against_oracle(backend, cfg, N, sch, nsteps=100, marks=(1, 10, 100)):
         if k in marks:
             out[k] = np.abs(f_d.uflat - f_o.uflat).max() / np.abs(f_o.uflat).max()
     return out
+
+
+def check_python_hook_stays_resident(backend):
+    """The README's hook is a Python function assigning two nodes (``fields.U[0] = 1``).  Those
+    assignments are applied on the device (``tf_poke``): the state is uploaded once and never
+    downloaded during the run, with and without the step-doubling wrapper, and the results are
+    the reference's."""
+    from triflow_amd import _capi
+    m = device_model("M1_advdiff", backend)
+    _, fdict, pars, dt, _ = corpus.config_inputs(1, 200)
+    g = np.load(os.path.join(GOLDEN, "simulation.npz"))
+    counts = dict(up=0, down=0, poke=0)
+    orig = {k: getattr(_capi.DeviceSolver, k) for k in ("set_state", "get_state", "get_state_flat", "poke")}
+
+    def counted(name, key):
+        def method(self, *a, **k):
+            counts[key] += 1
+            return orig[name](self, *a, **k)
+        return method
+    _capi.DeviceSolver.set_state = counted("set_state", "up")
+    _capi.DeviceSolver.get_state = counted("get_state", "down")
+    _capi.DeviceSolver.get_state_flat = counted("get_state_flat", "down")
+    _capi.DeviceSolver.poke = counted("poke", "poke")
+    try:
+        for ts in (False, True):
+            counts.update(up=0, down=0, poke=0)
+            sim = Simulation(m, fdict, pars, dt, hook=corpus.dirichlet_hook_cfg1, tmax=2.5,
+                             scheme=schemes.Theta, time_stepping=ts)
+            for t, fields in sim:
+                pass
+            # (step doubling starts its coarse and its first fine step from the same host container)
+            assert counts["up"] == (2 if ts else 1) and counts["down"] == 0 and counts["poke"] >= 4, (ts, counts)
+            U = fields.uflat
+            assert counts["down"] == 1
+            assert np.abs(U - g["Theta_ts%i_U" % ts][-1]).max() <= 1e-10, ts
+    finally:
+        for k, v in orig.items():
+            setattr(_capi.DeviceSolver, k, v)

@@ -99,3 +99,7 @@ def test_ensemble_equals_single_members(backend):
 def test_twenty_step_drift(backend):
     d = pc.drift_against_oracle(backend, 3, 400, "ROS2", nsteps=20, marks=(1, 20))
     assert d[1] <= 1e-11 and d[20] <= 1e-10, d
+
+
+def test_python_hook_stays_resident(backend):
+    pc.check_python_hook_stays_resident(backend)

@@ -257,3 +257,7 @@ def test_examples_run(script, args):
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     if script == "advection_diffusion.py":
         assert "t: 2.5" in res.stdout and res.stdout.count("iteration") == 5, res.stdout
+
+
+def test_python_hook_stays_resident():
+    pc.check_python_hook_stays_resident(HIP)

@@ -51,6 +51,7 @@ SIGNATURES = {
     "tf_set_x": (C.c_int, [C.c_void_p, c_double_p]),
     "tf_set_dirichlet": (C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int64_p, c_double_p]),
     "tf_set_dirichlet_values": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "tf_poke": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_int32_p, c_int64_p, c_double_p]),
     "tf_eval": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "tf_eval_repeat": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_double_p]),
     "tf_get_F": (C.c_int, [C.c_void_p, c_double_p]),
@@ -236,6 +237,17 @@ class DeviceSolver:
         node = np.array([e[1] for e in entries], dtype=np.int64)
         val = np.array([e[2] for e in entries], dtype=np.float64)
         self.lib.call("tf_set_dirichlet", self.handle, n,
+                      var.ctypes.data_as(c_int32_p), node.ctypes.data_as(c_int64_p), _dptr(val))
+
+    def poke(self, slot, entries):
+        """Point writes ``(variable index, node index, value)`` into a resident slot."""
+        entries = list(entries)
+        if not entries:
+            return
+        var = np.array([e[0] for e in entries], dtype=np.int32)
+        node = np.array([e[1] for e in entries], dtype=np.int64)
+        val = np.array([e[2] for e in entries], dtype=np.float64)
+        self.lib.call("tf_poke", self.handle, slot, len(entries),
                       var.ctypes.data_as(c_int32_p), node.ctypes.data_as(c_int64_p), _dptr(val))
 
     def set_dirichlet_values(self, before=None, after=None):

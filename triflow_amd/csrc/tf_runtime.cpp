@@ -127,6 +127,9 @@ struct tf_solver {
     int *dir_var = nullptr, *dir_node = nullptr;
     DevBuf dir_val, dir_val_post;   // values applied before the step (hook at t) / after (t+dt)
 
+    char* poke_buf = nullptr;      // scratch of tf_poke
+    size_t poke_bytes = 0;
+
     // BDF-2 history
     bool bdf_have_prev = false;
     double bdf_dt_prev = 0.0;
@@ -142,6 +145,7 @@ struct tf_solver {
     ~tf_solver() {
         for (auto& st : stamps) { tfb::event_destroy(st.a); tfb::event_destroy(st.b); }
         for (auto* e : event_pool) tfb::event_destroy(e);
+        if (poke_buf) tfb::dev_free(poke_buf);
         if (status) tfb::dev_free(status);
         if (dir_var) tfb::dev_free(dir_var);
         if (dir_node) tfb::dev_free(dir_node);
@@ -720,6 +724,41 @@ int tf_set_dirichlet(tf_solver* s, int32_t n, const int32_t* var, const int64_t*
         tfb::h2d(s->dir_val_post.p, value, sizeof(double) * n, s->stream);
         s->ndir = n;
     }
+    TF_API_END
+}
+
+// Point writes into a resident state slot (what a Python hook such as the README's
+// ``fields.U[0] = 1`` amounts to): n values, applied to every system of the solver.
+int tf_poke(tf_solver* s, int32_t slot, int32_t n, const int32_t* var, const int64_t* node, const double* value) {
+    TF_API_BEGIN
+    require(s, "null solver");
+    require(n >= 0, "tf_poke: n");
+    if (n == 0) return 0;
+    require(var && node && value, "tf_poke: null arrays");
+    std::vector<int> nodes(n);
+    for (int i = 0; i < n; ++i) {
+        require(var[i] >= 0 && var[i] < s->spec.nvar, "tf_poke: variable index");
+        require(node[i] >= -s->N && node[i] < s->N, "tf_poke: node index");
+        nodes[i] = (int)node[i];
+    }
+    // one packed upload into a scratch buffer that stays with the solver: [values | vars | nodes]
+    const size_t bytes = (size_t)n * (sizeof(double) + 2 * sizeof(int));
+    if (s->poke_bytes < bytes) {
+        if (s->poke_buf) tfb::dev_free(s->poke_buf);
+        s->poke_bytes = std::max<size_t>(bytes, 1024);
+        s->poke_buf = (char*)tfb::dev_alloc(s->poke_bytes);
+    }
+    std::vector<char> host(bytes);
+    std::memcpy(host.data(), value, sizeof(double) * n);
+    std::memcpy(host.data() + sizeof(double) * n, var, sizeof(int) * n);
+    std::memcpy(host.data() + sizeof(double) * n + sizeof(int) * n, nodes.data(), sizeof(int) * n);
+    tfb::h2d(s->poke_buf, host.data(), bytes, s->stream);       // returns when the copy has landed
+    TfDirichletArgs a;
+    a.L = s->L1; a.fields = s->st(slot); a.n = n;
+    a.value = (const double*)s->poke_buf;
+    a.var = (const int*)(s->poke_buf + sizeof(double) * n);
+    a.node = (const int*)(s->poke_buf + sizeof(double) * n + sizeof(int) * n);
+    s->launch(TFK_DIRICHLET, tf_solver::cdiv((int64_t)n * s->nsys, 64), 1, 64, &a, sizeof(a));
     TF_API_END
 }
 

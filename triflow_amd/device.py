@@ -154,7 +154,19 @@ class Stepper:
         """Slot holding the dependent variables of ``fields`` (uploads if needed)."""
         slot = self.resident_slot(fields)
         if slot is not None:
-            return slot
+            writes = fields._take_point_writes() if hasattr(fields, "_take_point_writes") else []
+            if not writes:
+                return slot
+            # a Python hook assigned single nodes (fields.U[0] = 1): the container is a copy
+            # of the state it came from, so the writes go to a slot of its own
+            dep = list(self.compiled.model._dep_vars)
+            dst = self.free_slot(exclude=(slot, *exclude))
+            self.solver.copy_state(slot, dst)
+            self.solver.poke(dst, [(dep.index(k), i, v) for k, i, v in writes])
+            backing = DeviceBacking(self, dst, self.slot_version[dst])
+            fields._attach_device(backing)
+            self._users[dst].append(weakref.ref(fields))
+            return dst
         slot = self.free_slot(exclude)
         dep = self.compiled.model._dep_vars
         self.solver.set_state(slot, np.array([np.asarray(fields[k]) for k in dep]))

@@ -71,7 +71,12 @@ def _device_step(model, t, fields, pars, hook, launch, dt=None):
 def _difference_norms(a, b, ord):
     """``||a[var] - b[var]||_ord`` for every dependent variable; computed by a
     reduction kernel when both containers still live on the same GPU solver."""
-    probe = lambda f: getattr(f, "_device_backing", lambda: None)()   # foreign containers: host norms
+    def probe(f):                       # foreign containers: host norms
+        backing = getattr(f, "_device_backing", lambda: None)()
+        if backing is not None and backing.valid() and f._pending_point_writes():
+            backing.stepper.acquire(f)      # node assignments of a Python hook: applied on the device
+            backing = f._device_backing()
+        return backing
     ba, bb = probe(a), probe(b)
     if ba is not None and bb is not None and ba.stepper is bb.stepper \
             and ba.valid() and bb.valid() and ord in (2, np.inf):
