@@ -108,6 +108,9 @@ int tf_set_dirichlet_values(tf_solver*, const double* before, const double* afte
    ``fields.U[0] = 1`` does, without moving the state over PCIe.                         */
 int tf_poke(tf_solver*, int32_t slot, int32_t n, const int32_t* var, const int64_t* node,
             const double* value);
+/* ... and the values of single nodes, out[i * nsys + system] */
+int tf_peek(tf_solver*, int32_t slot, int32_t n, const int32_t* var, const int64_t* node,
+            double* out);
 
 /* ---- seam #1: F / J evaluation on the resident state ----------------------- */
 int tf_eval(tf_solver*, int32_t slot, int32_t with_j);

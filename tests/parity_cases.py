@@ -569,3 +569,29 @@ def check_python_hook_stays_resident(backend):
     finally:
         for k, v in orig.items():
             setattr(_capi.DeviceSolver, k, v)
+
+
+def check_neumann_python_hook(backend):
+    """A hook that reads single nodes (zero-gradient ends, ``U[0] = U[1]``) stays on the device
+    (``tf_peek`` / ``tf_poke``) and gives what the oracle gives with the same hook."""
+    from triflow_amd import _capi
+
+    def hook(t, fields, pars):
+        fields.U[0] = fields.U[1]
+        fields.U[-1] = fields.U[-2]
+        return fields, pars
+    m, mo = device_model("M1_advdiff", backend), oracle_model("M1_advdiff")
+    _, fdict, pars, dt, _ = corpus.config_inputs(1, 200)
+    downloads = []
+    orig = _capi.DeviceSolver.get_state
+    _capi.DeviceSolver.get_state = lambda self, *a, **k: (downloads.append(1), orig(self, *a, **k))[1]
+    try:
+        dev, ref = schemes.Theta(m), ora.Theta(mo)
+        f_d, f_o, t = m.fields_template(**fdict), mo.fields_template(**fdict), 0.0
+        for _ in range(6):
+            _, f_d = dev(t, f_d, dt, pars, hook=hook)
+            t, f_o = ref(t, f_o, dt, pars, hook=hook)
+        assert not downloads
+    finally:
+        _capi.DeviceSolver.get_state = orig
+    assert np.abs(f_d.uflat - f_o.uflat).max() <= 1e-12

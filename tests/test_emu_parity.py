@@ -103,3 +103,7 @@ def test_twenty_step_drift(backend):
 
 def test_python_hook_stays_resident(backend):
     pc.check_python_hook_stays_resident(backend)
+
+
+def test_neumann_python_hook(backend):
+    pc.check_neumann_python_hook(backend)

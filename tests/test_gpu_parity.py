@@ -261,3 +261,7 @@ def test_examples_run(script, args):
 
 def test_python_hook_stays_resident():
     pc.check_python_hook_stays_resident(HIP)
+
+
+def test_neumann_python_hook():
+    pc.check_neumann_python_hook(HIP)

@@ -52,6 +52,7 @@ SIGNATURES = {
     "tf_set_dirichlet": (C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int64_p, c_double_p]),
     "tf_set_dirichlet_values": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "tf_poke": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_int32_p, c_int64_p, c_double_p]),
+    "tf_peek": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_int32_p, c_int64_p, c_double_p]),
     "tf_eval": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "tf_eval_repeat": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_double_p]),
     "tf_get_F": (C.c_int, [C.c_void_p, c_double_p]),
@@ -249,6 +250,15 @@ class DeviceSolver:
         val = np.array([e[2] for e in entries], dtype=np.float64)
         self.lib.call("tf_poke", self.handle, slot, len(entries),
                       var.ctypes.data_as(c_int32_p), node.ctypes.data_as(c_int64_p), _dptr(val))
+
+    def peek(self, slot, var, node):
+        """Value of one node of a resident slot (per system)."""
+        v = np.array([var], dtype=np.int32)
+        n = np.array([node], dtype=np.int64)
+        out = np.empty((1, self.nsys))
+        self.lib.call("tf_peek", self.handle, slot, 1, v.ctypes.data_as(c_int32_p),
+                      n.ctypes.data_as(c_int64_p), _dptr(out))
+        return out[0]
 
     def set_dirichlet_values(self, before=None, after=None):
         b = _f64(before) if before is not None else None

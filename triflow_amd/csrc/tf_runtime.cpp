@@ -762,6 +762,31 @@ int tf_poke(tf_solver* s, int32_t slot, int32_t n, const int32_t* var, const int
     TF_API_END
 }
 
+// Values of single nodes of a resident slot (a Python hook reading a neighbour, e.g. the
+// zero-gradient condition ``fields.U[0] = fields.U[1]``): out[i * nsys + e].
+int tf_peek(tf_solver* s, int32_t slot, int32_t n, const int32_t* var, const int64_t* node, double* out) {
+    TF_API_BEGIN
+    require(s, "null solver");
+    require(n >= 0, "tf_peek: n");
+    if (n == 0) return 0;
+    require(var && node && out, "tf_peek: null arrays");
+    const TfLayout& L = s->L1;
+    const int big = L.rem * (L.mbase + 1);
+    for (int i = 0; i < n; ++i) {
+        require(var[i] >= 0 && var[i] < s->spec.nvar, "tf_peek: variable index");
+        require(node[i] >= -s->N && node[i] < s->N, "tf_peek: node index");
+        const int g = (int)(node[i] < 0 ? node[i] + s->N : node[i]);
+        int p, li;                                         // node -> (chunk, row), as tf_locate
+        if (g < big) { p = g / (L.mbase + 1); li = g - p * (L.mbase + 1); }
+        else { const int h = g - big; p = L.rem + h / L.mbase; li = h - (h / L.mbase) * L.mbase; }
+        for (int e = 0; e < s->nsys; ++e) {
+            const int64_t off = (int64_t)var[i] * L.plane + (int64_t)li * L.Ptot + (e * L.P + p);
+            tfb::d2h(out + (int64_t)i * s->nsys + e, s->st(slot) + off, sizeof(double), s->stream);
+        }
+    }
+    TF_API_END
+}
+
 // --------------------------------------------------------------- seam #1
 int tf_set_dirichlet_values(tf_solver* s, const double* before, const double* after) {
     TF_API_BEGIN
