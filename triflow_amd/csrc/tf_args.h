@@ -108,6 +108,18 @@ struct TfDirichletArgs {
     const double* value;
 };
 
+// A few point writes passed by value (tf_poke: node assignments of a Python hook); no
+// device arrays, so the launch needs no upload and no synchronisation.
+#define TF_POKE_MAX 8
+struct TfPokeArgs {
+    TfLayout L;
+    double* fields;
+    int n;
+    int var[TF_POKE_MAX];
+    int node[TF_POKE_MAX];
+    double value[TF_POKE_MAX];
+};
+
 // One level of the banded solver.  Level 1 reads its block rows from the
 // Jacobian planes (A = I - c J, built on the fly); levels >= 2 read the
 // explicit block-tridiagonal reduced system produced by the level below.
@@ -178,11 +190,11 @@ enum TfKernel {
     TFK_L1_FACTOR, TFK_L1_SOLVE, TFK_L1_ASM_MAT, TFK_L1_ASM_RHS, TFK_L1_BACKSUB,
     TFK_BT_LU, TFK_BT_SPIKE, TFK_BT_RHS, TFK_BT_ASM_MAT, TFK_BT_ASM_RHS, TFK_BT_BACKSUB,
     TFK_TOP_FACTOR, TFK_TOP_SOLVE, TFK_BERR, TFK_DIFFNORM, TFK_L1_FACTOR_RHS, TFK_SWEEP_F_STAGE,
-    TFK_CR_FACTOR, TFK_CR_FWD, TFK_CR_BWD, TFK_COUNT
+    TFK_CR_FACTOR, TFK_CR_FWD, TFK_CR_BWD, TFK_POKE, TFK_COUNT
 };
 #define TF_KERNEL_NAMES { \
     "tfk_sweep_f", "tfk_sweep_fj", "tfk_spmv", "tfk_vec", "tfk_vec_maxabs", "tfk_perm", "tfk_dirichlet", \
     "tfk_l1_factor", "tfk_l1_solve", "tfk_l1_asm_mat", "tfk_l1_asm_rhs", "tfk_l1_backsub", \
     "tfk_bt_lu", "tfk_bt_spike", "tfk_bt_rhs", "tfk_bt_asm_mat", "tfk_bt_asm_rhs", "tfk_bt_backsub", \
     "tfk_top_factor", "tfk_top_solve", "tfk_berr", "tfk_diffnorm", "tfk_l1_factor_rhs", "tfk_sweep_f_stage", \
-    "tfk_cr_factor", "tfk_cr_fwd", "tfk_cr_bwd" }
+    "tfk_cr_factor", "tfk_cr_fwd", "tfk_cr_bwd", "tfk_poke" }

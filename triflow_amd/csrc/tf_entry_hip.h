@@ -99,6 +99,9 @@ __global__ void __launch_bounds__(256) tfk_perm(TfPermArgs a) {
 __global__ void __launch_bounds__(64) tfk_dirichlet(TfDirichletArgs a) {
     tfk_dirichlet_elem(a, TF_GID);
 }
+__global__ void __launch_bounds__(64) tfk_poke(TfPokeArgs a) {
+    tfk_poke_elem(a, TF_GID);
+}
 
 // ---- banded solver, level 1 (rows from the Jacobian planes) ----------------
 // grid.y: 0 = walk down, 1 = walk up (wave-uniform)

@@ -362,6 +362,21 @@ TF_DEVICE void tfk_dirichlet_elem(const TfDirichletArgs& a, int t) {
     a.fields[(int64_t)a.var[k] * L.plane + tf_idx(L, e * L.P + p, i)] = a.value[k];
 }
 
+TF_DEVICE void tfk_poke_elem(const TfPokeArgs& a, int t) {
+    const TfLayout& L = a.L;
+    if (t >= a.n * L.nsys) return;
+    const int k = t % a.n, e = t / a.n;
+    int g = 0, v = 0;
+    double val = 0.0;
+#pragma unroll
+    for (int q = 0; q < TF_POKE_MAX; ++q)          // by-value arrays: no dynamic indexing
+        if (q == k) { g = a.node[q]; v = a.var[q]; val = a.value[q]; }
+    if (g < 0) g += L.N;
+    int p, i;
+    tf_locate(L, g, p, i);
+    a.fields[(int64_t)v * L.plane + tf_idx(L, e * L.P + p, i)] = val;
+}
+
 // ===========================================================================
 // 5. block-banded direct solver
 // ===========================================================================

@@ -741,6 +741,15 @@ int tf_poke(tf_solver* s, int32_t slot, int32_t n, const int32_t* var, const int
         require(node[i] >= -s->N && node[i] < s->N, "tf_poke: node index");
         nodes[i] = (int)node[i];
     }
+    if (n <= TF_POKE_MAX) {
+        // the usual case (a couple of boundary nodes): passed by value with the launch
+        TfPokeArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.L = s->L1; a.fields = s->st(slot); a.n = n;
+        for (int i = 0; i < n; ++i) { a.var[i] = var[i]; a.node[i] = nodes[i]; a.value[i] = value[i]; }
+        s->launch(TFK_POKE, tf_solver::cdiv((int64_t)n * s->nsys, 64), 1, 64, &a, sizeof(a));
+        return 0;
+    }
     // one packed upload into a scratch buffer that stays with the solver: [values | vars | nodes]
     const size_t bytes = (size_t)n * (sizeof(double) + 2 * sizeof(int));
     if (s->poke_bytes < bytes) {
