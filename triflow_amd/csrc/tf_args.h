@@ -182,6 +182,8 @@ struct TfTopArgs {                 // final 1-node system per ensemble member
 
 // nodes per chunk of a cyclic-reduction level (one wavefront: 8 nodes x 8 lanes per round)
 #define TF_CR_MAXLEN 16
+// ... and of the scalar variant (b <= 2: one thread per node, 256-thread workgroups)
+#define TF_CRS_MAXLEN 256
 
 // Kernel table: index = launch id used by the runtime, name = entry point in
 // the per-model code object (tf_entry_hip.h).

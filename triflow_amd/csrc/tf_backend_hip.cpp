@@ -29,7 +29,7 @@ bool cyclic_reduction(int b) {
     // TRIFLOW_REDUCED=walk selects the chunk walks of tfk_bt_* instead (A/B comparisons)
     const char* mode = getenv("TRIFLOW_REDUCED");
     if (mode && std::string(mode) == "walk") return false;
-    return b >= 3 && b <= 8;
+    return b >= 1 && b <= 8;
 }
 
 int device_count() {

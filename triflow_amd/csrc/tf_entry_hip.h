@@ -159,15 +159,20 @@ __global__ void __launch_bounds__(64) tfk_top_factor(TfTopArgs a) {
 }
 __global__ void __launch_bounds__(64) tfk_top_solve(TfTopArgs a) { tfk_top_body<TF_B2, false>(a, TF_GID); }
 
-// ---- cyclic-reduction levels (tf_coop_hip.h): one wavefront per chunk, 3 <= b <= 8
-__global__ void __launch_bounds__(64) tfk_cr_factor(TfLevelArgs a) {
-    if constexpr (TF_B2 >= 3 && TF_B2 <= 8) tfk_cr_factor_coop<TF_B2>(a);
+// ---- cyclic-reduction levels (tf_coop_hip.h): 3 <= b <= 8 one wavefront per 16-node chunk
+//      (8 lanes per node); b <= 2 one thread per node, 256-node chunks
+#define TF_CR_BLOCK (TF_B2 <= 2 ? 256 : 64)
+__global__ void __launch_bounds__(TF_CR_BLOCK) tfk_cr_factor(TfLevelArgs a) {
+    if constexpr (TF_B2 <= 2) tfk_crs_factor<TF_B2>(a);
+    else if constexpr (TF_B2 <= 8) tfk_cr_factor_coop<TF_B2>(a);
 }
-__global__ void __launch_bounds__(64) tfk_cr_fwd(TfLevelArgs a) {
-    if constexpr (TF_B2 >= 3 && TF_B2 <= 8) tfk_cr_fwd_coop<TF_B2>(a);
+__global__ void __launch_bounds__(TF_CR_BLOCK) tfk_cr_fwd(TfLevelArgs a) {
+    if constexpr (TF_B2 <= 2) tfk_crs_fwd<TF_B2>(a);
+    else if constexpr (TF_B2 <= 8) tfk_cr_fwd_coop<TF_B2>(a);
 }
-__global__ void __launch_bounds__(64) tfk_cr_bwd(TfLevelArgs a) {
-    if constexpr (TF_B2 >= 3 && TF_B2 <= 8) tfk_cr_bwd_coop<TF_B2>(a);
+__global__ void __launch_bounds__(TF_CR_BLOCK) tfk_cr_bwd(TfLevelArgs a) {
+    if constexpr (TF_B2 <= 2) tfk_crs_bwd<TF_B2>(a);
+    else if constexpr (TF_B2 <= 8) tfk_cr_bwd_coop<TF_B2>(a);
 }
 
 }  // extern "C"

@@ -95,6 +95,7 @@ struct tf_solver {
     bool use_cr = false;   // the back end has the cyclic-reduction kernels (tfk_cr_*) for this block size
     // storage of what a level hands to the next one: records per node (below a cyclic-
     // reduction level) or partition-interleaved planes
+    unsigned cr_block() const { return top.B <= 2 ? 256u : 64u; }     // TF_CR_BLOCK of tf_entry_hip.h
     // the last level is a cyclic-reduction level: it handles the top block itself
     bool fold_top() const { return levels.size() > 1 && levels.back()->cr; }
     bool level_cr(size_t l) const { return l < levels.size() && levels[l]->cr; }
@@ -326,7 +327,7 @@ struct tf_solver {
             else if (levels[l]->cr) {
                 // one wavefront per chunk; leaves the next level's rows (and rhs) behind
                 a.cr_rhs = fused ? 1 : 0;
-                launch(TFK_CR_FACTOR, (unsigned)a.L.Ptot, 1, 64, &a, sizeof(a));
+                launch(TFK_CR_FACTOR, (unsigned)a.L.Ptot, 1, cr_block(), &a, sizeof(a));
                 continue;
             } else {
                 const int G = tfb::coop_group(levels[l]->B);
@@ -358,7 +359,7 @@ struct tf_solver {
         for (size_t l = levels.size() - (skip_last ? 1 : 0); l-- > 0;) {
             TfLevelArgs a = level_args(l, rhs1, x1);
             if (l == 0) launch(TFK_L1_BACKSUB, cdiv(a.L.Ptot, 64), 1, 64, &a, sizeof(a));
-            else if (levels[l]->cr) launch(TFK_CR_BWD, (unsigned)a.L.Ptot, 1, 64, &a, sizeof(a));
+            else if (levels[l]->cr) launch(TFK_CR_BWD, (unsigned)a.L.Ptot, 1, cr_block(), &a, sizeof(a));
             else launch(TFK_BT_BACKSUB, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
         }
     }
@@ -367,7 +368,7 @@ struct tf_solver {
             TfLevelArgs a = level_args(l, rhs1, x1);
             unsigned gx = cdiv(a.L.Ptot, 64);
             if (l == 0) launch(TFK_L1_SOLVE, gx, 2, 64, &a, sizeof(a));
-            else if (levels[l]->cr) { launch(TFK_CR_FWD, (unsigned)a.L.Ptot, 1, 64, &a, sizeof(a)); continue; }
+            else if (levels[l]->cr) { launch(TFK_CR_FWD, (unsigned)a.L.Ptot, 1, cr_block(), &a, sizeof(a)); continue; }
             else launch(TFK_BT_RHS, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 2, 64, &a, sizeof(a));
             if (l == 0) launch(TFK_L1_ASM_RHS, gx, 1, 64, &a, sizeof(a));
             else launch(TFK_BT_ASM_RHS, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
@@ -525,7 +526,11 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
         // tools/gpu_small_n_scan.py (N = 200 ... 4e5) and tools/gpu_plan_scan.sh (N = 1e6).
         const int64_t total = (int64_t)N * nsys;
         m1 = 32;
-        if (s->use_cr) m1 = total <= 30000 ? 4 : (total <= 200000 ? 8 : (total <= 600000 ? 16 : 32));
+        // (not for a single equation with a 5-point stencil: dispersion-dominated ones -- KdV --
+        // lose digits with every separator, tools/gpu_scalar_m1.py, so they keep long chunks)
+        const bool dispersive_capable = sp.nvar == 1 && sp.mp >= 2;
+        if (s->use_cr && !dispersive_capable)
+            m1 = total <= 30000 ? 4 : (total <= 200000 ? 8 : (total <= 600000 ? 16 : 32));
     }
     m1 = std::max(m1, 2 * sp.mp);
     {
@@ -533,8 +538,10 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
         // per 16-node chunk does about twice the arithmetic of the walks (later rounds leave
         // lanes idle).  Levels with more nodes than cr_max_nodes (all ensemble members
         // together; ~10 wavefronts per CU, scanned with tools/gpu_cr_scan.sh) keep the walks.
-        const int cr_len = opts && opts->m_upper > 0 ? std::min(std::max(opts->m_upper, 2), TF_CR_MAXLEN) : TF_CR_MAXLEN;
-        int64_t cr_max_nodes = 40000;
+        // (scalar models, b <= 2: one thread per node, chunks of 256, no such limit)
+        const int cr_cap = b2 <= 2 ? TF_CRS_MAXLEN : TF_CR_MAXLEN;
+        const int cr_len = opts && opts->m_upper > 0 ? std::min(std::max(opts->m_upper, 2), cr_cap) : cr_cap;
+        int64_t cr_max_nodes = b2 <= 2 ? ((int64_t)1 << 40) : 40000;
         if (const char* v = getenv("TRIFLOW_CR_MAX_NODES")) cr_max_nodes = atoll(v);
         int n = (int)N, B = sp.nvar, MP = sp.mp, m = m1;
         bool first = true;
