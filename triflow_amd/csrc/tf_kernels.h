@@ -86,7 +86,7 @@ TF_DEVICE int64_t tf_next_x(const TfLevelArgs& a, int e, int p, int64_t s2, int 
 // 1. F / F+J stencil sweep                       (compilers.py:227-332)
 // ===========================================================================
 // grid: x over chunks (all systems), y over segments of TF_SEG nodes.
-template <bool WITH_J, bool STAGE = false>
+template <bool WITH_J, bool STAGE = false, bool THETA = false>
 TF_DEVICE void tfk_sweep_body(const TfSweepArgs& a, int pg, int seg) {
     const TfLayout& L = a.L;
     if (pg >= L.Ptot) return;
@@ -142,6 +142,22 @@ TF_DEVICE void tfk_sweep_body(const TfSweepArgs& a, int pg, int seg) {
                 tf_eval_J(w, par, dx, xc, Jo);
 #pragma unroll
                 for (int k = 0; k < TF_NNZ; ++k) TF_STORE_STREAM(&a.Jv[(int64_t)k * L.plane + s], Jo[k]);
+                if (THETA) {
+                    // rhs of the theta scheme from the same window: the operations of
+                    // tfk_spmv_body (scale = theta) followed by TF_VEC_THETA_RHS
+                    double acc[TF_NVAR];
+#pragma unroll
+                    for (int v = 0; v < TF_NVAR; ++v) acc[v] = 0.0;
+#pragma unroll
+                    for (int k = 0; k < TF_NNZ; ++k) {
+                        const double jv = a.theta * Jo[k];
+                        acc[tf_pat_eq[k]] = acc[tf_pat_eq[k]] + jv * w[tf_pat_var[k]][tf_pat_off[k] + TF_MP];
+                    }
+#pragma unroll
+                    for (int v = 0; v < TF_NVAR; ++v)
+                        a.theta_rhs[(int64_t)v * L.plane + s] =
+                            a.theta_dt * (a.fscale * Fo[v] - acc[v]) + w[v][TF_MP];
+                }
             }
         }
     }

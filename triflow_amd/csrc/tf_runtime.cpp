@@ -255,6 +255,18 @@ struct tf_solver {
                spec.sweep_block, &a, sizeof(a));
         if (with_j) { have_jac = true; have_factor = false; }
     }
+    // F, J and rhs = dt*(F - theta*J@U) + U of the theta scheme in one pass
+    void sweep_theta(const double* fields, double dt, double theta, double* rhs) {
+        TfSweepArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.fscale = 1.0;
+        a.L = L1; a.fields = fields; a.helpers = helpers.p; a.parvec = parvec.p; a.parsca = parsca.p;
+        a.dx = dx.p; a.xcoord = xcoord.p; a.F = F.p; a.Jv = Jv.p; a.with_j = 1;
+        a.theta_rhs = rhs; a.theta = theta; a.theta_dt = dt;
+        unsigned gx = cdiv(L1.Ptot, spec.sweep_block), gy = cdiv(L1.M, spec.seg);
+        launch(TFK_SWEEP_FJ_THETA, gx, gy, spec.sweep_block, &a, sizeof(a));
+        have_jac = true; have_factor = false;
+    }
     void spmv(const double* v, double* y, double scale, bool absval = false) {
         TfSpmvArgs a;
         std::memset(&a, 0, sizeof(a));
@@ -887,11 +899,7 @@ int tf_step_theta(tf_solver* s, int32_t src, int32_t dst, double dt, double thet
     require(src != dst, "tf_step_theta: src and dst slots must differ");
     double* U = s->st(dst);
     const double* Uin = s->stage_input(src, U);                    // copy + hook only when there is a hook
-    s->sweep(Uin, true);
-    s->spmv(Uin, s->Wjv.p, theta);                                 // (theta*J) @ U
-    const double* xs[3] = {s->F.p, s->Wjv.p, Uin};
-    const double cs[3] = {dt, 0, 0};
-    s->vec(TF_VEC_THETA_RHS, s->Wrhs.p, nullptr, 3, xs, cs);       // dt*(F - .) + U
+    s->sweep_theta(Uin, dt, theta, s->Wrhs.p);                     // F, J, dt*(F - (theta*J)@U) + U
     s->factor(theta * dt, s->Wrhs.p, U);
     s->apply_dirichlet(U, true);
     TF_API_END
