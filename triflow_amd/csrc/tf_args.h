@@ -48,6 +48,12 @@ struct TfSweepArgs {               // F / F+J stencil sweep, J @ v, A-row build
     //   rhs = dt * (F - (theta * J) @ U) + U        (schemes.py:553-556)
     double* theta_rhs;
     double theta, theta_dt;
+    // tfk_sweep_fj_bdf2: right-hand side of the linearly implicit BDF-2 step and the history
+    // update in the same pass:  rhs = c0*(U - Uprev) + c1*F (two_step) or c1*F;  Uprev <- U
+    double* bdf_rhs;
+    double* bdf_prev;
+    double bdf_c0, bdf_c1;
+    int bdf_two_step;
 };
 
 struct TfSpmvArgs {                // y = scale * J @ v  (clamped/wrapped columns)
@@ -196,11 +202,11 @@ enum TfKernel {
     TFK_L1_FACTOR, TFK_L1_SOLVE, TFK_L1_ASM_MAT, TFK_L1_ASM_RHS, TFK_L1_BACKSUB,
     TFK_BT_LU, TFK_BT_SPIKE, TFK_BT_RHS, TFK_BT_ASM_MAT, TFK_BT_ASM_RHS, TFK_BT_BACKSUB,
     TFK_TOP_FACTOR, TFK_TOP_SOLVE, TFK_BERR, TFK_DIFFNORM, TFK_L1_FACTOR_RHS, TFK_SWEEP_F_STAGE,
-    TFK_CR_FACTOR, TFK_CR_FWD, TFK_CR_BWD, TFK_POKE, TFK_SWEEP_FJ_THETA, TFK_COUNT
+    TFK_CR_FACTOR, TFK_CR_FWD, TFK_CR_BWD, TFK_POKE, TFK_SWEEP_FJ_THETA, TFK_SWEEP_FJ_BDF2, TFK_COUNT
 };
 #define TF_KERNEL_NAMES { \
     "tfk_sweep_f", "tfk_sweep_fj", "tfk_spmv", "tfk_vec", "tfk_vec_maxabs", "tfk_perm", "tfk_dirichlet", \
     "tfk_l1_factor", "tfk_l1_solve", "tfk_l1_asm_mat", "tfk_l1_asm_rhs", "tfk_l1_backsub", \
     "tfk_bt_lu", "tfk_bt_spike", "tfk_bt_rhs", "tfk_bt_asm_mat", "tfk_bt_asm_rhs", "tfk_bt_backsub", \
     "tfk_top_factor", "tfk_top_solve", "tfk_berr", "tfk_diffnorm", "tfk_l1_factor_rhs", "tfk_sweep_f_stage", \
-    "tfk_cr_factor", "tfk_cr_fwd", "tfk_cr_bwd", "tfk_poke", "tfk_sweep_fj_theta" }
+    "tfk_cr_factor", "tfk_cr_fwd", "tfk_cr_bwd", "tfk_poke", "tfk_sweep_fj_theta", "tfk_sweep_fj_bdf2" }

@@ -30,6 +30,9 @@ __global__ void TF_SWEEP_ATTR __launch_bounds__(TF_SWEEP_BLOCK) tfk_sweep_fj(TfS
 __global__ void TF_SWEEP_ATTR __launch_bounds__(TF_SWEEP_BLOCK) tfk_sweep_fj_theta(TfSweepArgs a) {
     tfk_sweep_body<true, false, true>(a, TF_GID, blockIdx.y);
 }
+__global__ void TF_SWEEP_ATTR __launch_bounds__(TF_SWEEP_BLOCK) tfk_sweep_fj_bdf2(TfSweepArgs a) {
+    tfk_sweep_body<true, false, false, true>(a, TF_GID, blockIdx.y);
+}
 __global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_spmv(TfSpmvArgs a) {
     tfk_spmv_body(a, TF_GID, blockIdx.y);
 }

@@ -86,7 +86,7 @@ TF_DEVICE int64_t tf_next_x(const TfLevelArgs& a, int e, int p, int64_t s2, int 
 // 1. F / F+J stencil sweep                       (compilers.py:227-332)
 // ===========================================================================
 // grid: x over chunks (all systems), y over segments of TF_SEG nodes.
-template <bool WITH_J, bool STAGE = false, bool THETA = false>
+template <bool WITH_J, bool STAGE = false, bool THETA = false, bool BDF = false>
 TF_DEVICE void tfk_sweep_body(const TfSweepArgs& a, int pg, int seg) {
     const TfLayout& L = a.L;
     if (pg >= L.Ptot) return;
@@ -142,6 +142,17 @@ TF_DEVICE void tfk_sweep_body(const TfSweepArgs& a, int pg, int seg) {
                 tf_eval_J(w, par, dx, xc, Jo);
 #pragma unroll
                 for (int k = 0; k < TF_NNZ; ++k) TF_STORE_STREAM(&a.Jv[(int64_t)k * L.plane + s], Jo[k]);
+                if (BDF) {
+                    // TF_VEC_BDF2_RHS and the copy of U into the history, per node
+#pragma unroll
+                    for (int v = 0; v < TF_NVAR; ++v) {
+                        const double u = w[v][TF_MP];
+                        const int64_t q = (int64_t)v * L.plane + s;
+                        a.bdf_rhs[q] = a.bdf_two_step ? a.bdf_c0 * (u - a.bdf_prev[q]) + a.bdf_c1 * Fo[v]
+                                                      : a.bdf_c1 * Fo[v];
+                        a.bdf_prev[q] = u;
+                    }
+                }
                 if (THETA) {
                     // rhs of the theta scheme from the same window: the operations of
                     // tfk_spmv_body (scale = theta) followed by TF_VEC_THETA_RHS

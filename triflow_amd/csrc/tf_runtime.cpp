@@ -255,6 +255,18 @@ struct tf_solver {
                spec.sweep_block, &a, sizeof(a));
         if (with_j) { have_jac = true; have_factor = false; }
     }
+    // F, J, the BDF-2 right-hand side and the history update Uprev <- U in one pass
+    void sweep_bdf2(const double* fields, bool two_step, double c0, double c1, double* rhs, double* prev) {
+        TfSweepArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.fscale = 1.0;
+        a.L = L1; a.fields = fields; a.helpers = helpers.p; a.parvec = parvec.p; a.parsca = parsca.p;
+        a.dx = dx.p; a.xcoord = xcoord.p; a.F = F.p; a.Jv = Jv.p; a.with_j = 1;
+        a.bdf_rhs = rhs; a.bdf_prev = prev; a.bdf_c0 = c0; a.bdf_c1 = c1; a.bdf_two_step = two_step ? 1 : 0;
+        unsigned gx = cdiv(L1.Ptot, spec.sweep_block), gy = cdiv(L1.M, spec.seg);
+        launch(TFK_SWEEP_FJ_BDF2, gx, gy, spec.sweep_block, &a, sizeof(a));
+        have_jac = true; have_factor = false;
+    }
     // F, J and rhs = dt*(F - theta*J@U) + U of the theta scheme in one pass
     void sweep_theta(const double* fields, double dt, double theta, double* rhs) {
         TfSweepArgs a;
@@ -961,16 +973,9 @@ int tf_step_bdf2(tf_solver* s, int32_t src, int32_t dst, double dt) {
     const double* Uin = s->stage_input(src, U);
     const bool two_step = s->bdf_have_prev &&
         std::fabs(s->bdf_dt_prev - dt) <= 1e-12 * std::fabs(dt);
-    s->sweep(Uin, true, 0, nullptr, nullptr, two_step ? 1.0 : dt);
-    const double* rhs = s->F.p;                                    // dt*F on a first step
-    if (two_step) {
-        const double* xs[3] = {Uin, s->Uprev.p, s->F.p};
-        const double cs[3] = {1.0 / 3.0, (2.0 / 3.0) * dt, 0};
-        s->vec(TF_VEC_BDF2_RHS, s->Wrhs.p, nullptr, 3, xs, cs);
-        rhs = s->Wrhs.p;
-    }
-    const double* cp[1] = {Uin};
-    s->vec(TF_VEC_COPY, s->Uprev.p, nullptr, 1, cp, nullptr);
+    // rhs = 1/3 (U - Uprev) + 2/3 dt F (two-step) or dt F (first step), and Uprev <- U
+    s->sweep_bdf2(Uin, two_step, 1.0 / 3.0, two_step ? (2.0 / 3.0) * dt : dt, s->Wrhs.p, s->Uprev.p);
+    const double* rhs = s->Wrhs.p;
     s->bdf_have_prev = true;
     s->bdf_dt_prev = dt;
     s->factor(two_step ? (2.0 / 3.0) * dt : dt, rhs, s->Wdel.p);
