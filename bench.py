@@ -36,6 +36,24 @@ def sweep_bytes_per_node(model):
     return 8 * (nvar + nh) + 8 * nvar + 8 * nnz
 
 
+def step_bytes_per_node(model, scheme, stages):
+    """Algorithmic bytes of one implicit step ("implicit step"):
+    F+J sweep, (s-1) F-only sweeps, one factorisation (write LU + read LU:
+    2*8*W*nvar^2), s solves (8*W*nvar^2 + 16*nvar each) and (s-1) band products
+    J@v (8*nnz + 16*nvar); Theta / BDF-2: sweep + read U + factor/solve streaming
+    + rhs in, x out, U out (+ the history read/write for BDF-2)."""
+    nvar = model._nvar
+    nh = len(model._help_funcs)
+    nnz = len(model._J_sparse_array)
+    W = model._window_range
+    sweep = sweep_bytes_per_node(model)
+    if scheme in ("Theta", "BDF2"):
+        return sweep + 8 * nvar + 16 * W * nvar ** 2 + 24 * nvar + (16 * nvar if scheme == "BDF2" else 0)
+    fsweep = 8 * (nvar + nh) + 8 * nvar
+    return (sweep + (stages - 1) * fsweep + 16 * W * nvar ** 2
+            + stages * (8 * W * nvar ** 2 + 16 * nvar) + (stages - 1) * (8 * nnz + 16 * nvar))
+
+
 def member_table(n_members, base):
     """Parameter sweep of BASELINE config 4: c = 0.5 + m/64,
     We = 0.005 * (1 + m % 8), initial-condition phase 2*pi*m/64."""
@@ -121,16 +139,29 @@ def scheme_api_rate(model, cfg, N, scheme_name, dt, steps=20):
     return steps / (time.perf_counter() - t0)
 
 
+def _device_identity(torch, index):
+    """What identifies the physical GPU a rank runs on (for the N > 1 line)."""
+    props = torch.cuda.get_device_properties(index)
+    ident = getattr(props, "uuid", None)
+    bus = getattr(props, "pci_bus_id", None)
+    return "%s|uuid=%s|pci=%s" % (props.name, ident, bus)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=25,
+                    help="the timed K-step block is repeated this many times, each bracketed by "
+                         "barrier + synchronize; value / ms_per_step are those of the median block")
     ap.add_argument("--members-per-gpu", type=int, default=1)
     ap.add_argument("--config", type=int, default=3, choices=(2, 3, 5))
     ap.add_argument("--nodes", type=int, default=0, help="override N (default: BASELINE size)")
     ap.add_argument("--scheme", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--plain", action="store_true",
+                    help="only the timed loop (profiler runs): no per-kernel pass, no Python-protocol rate")
     ap.add_argument("--cpu-workers", type=int, default=0,
                     help="also time the CPU baseline with this many member processes (ensemble runs)")
     args = ap.parse_args()
@@ -138,6 +169,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(args.gpus, 1):
+        raise SystemExit("bench.py --gpus %d needs %d ranks (torch.distributed.run --nproc-per-node), "
+                         "WORLD_SIZE is %d" % (args.gpus, args.gpus, world))
     import torch
     dist = None
     # rehearsal on a one-GPU box: TRIFLOW_BENCH_BACKEND=gloo puts every rank on GPU 0
@@ -178,43 +212,65 @@ def main():
     for _ in range(args.warmup):
         ens.step(dt)
     # HIP events (kernel begin/end timestamps) on the roofline kernel only, so the
-    # timed region is not perturbed by instrumenting all ~70 launches per step
-    solver.timing(kernels=["tfk_sweep_fj"])
+    # timed region is not perturbed by instrumenting every launch of a step
+    sweep_kernel = {"Theta": "tfk_sweep_fj_theta", "BDF2": "tfk_sweep_fj_bdf2"}.get(scheme, "tfk_sweep_fj")
+    solver.timing(kernels=[sweep_kernel])
     solver.timing_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ens.step(dt)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    sweep_ms, sweep_n = solver.timing_report().get("tfk_sweep_fj", (0.0, 0))
-    # untimed pass with every launch instrumented: per-kernel breakdown
-    nprof = min(args.steps, 10)
-    solver.timing(True)
-    solver.timing_reset()
-    for _ in range(nprof):
-        ens.step(dt)
-    ens.sync()
-    report = solver.timing_report()
+    blocks = []
+    for _ in range(max(args.repeats, 1)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):           # EXACTLY K steps between the two barriers
+            ens.step(dt)
+        barrier()
+        blocks.append(time.perf_counter() - t0)
+    sweep_ms, sweep_n = solver.timing_report().get(sweep_kernel, (0.0, 0))
     solver.timing(False)
+    ens.check()                                # a singular / unstable factorisation raises here
+    report, nprof = {}, 0
+    if not args.plain:
+        # untimed pass with every launch instrumented: per-kernel breakdown
+        nprof = min(args.steps, 10)
+        solver.timing(True)
+        solver.timing_reset()
+        for _ in range(nprof):
+            ens.step(dt)
+        ens.sync()
+        report = solver.timing_report()
+        solver.timing(False)
+    blocks = np.asarray(blocks)
+    seen = None
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64,
-                            device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        tdev = "cuda" if backend == "nccl" else "cpu"
+        tb = torch.tensor(blocks, dtype=torch.float64, device=tdev)
+        gathered = [torch.zeros_like(tb) for _ in range(world)]
+        dist.all_gather(gathered, tb)
+        per_rank = np.stack([g.cpu().numpy() for g in gathered])         # [rank][block]
+        blocks = per_rank.max(axis=0)                                    # MAX over ranks, per block
+        seen = [None] * world
+        dist.all_gather_object(seen, dict(rank=rank, local_rank=local_rank, members=len(mine),
+                                          device=_device_identity(torch, device_index),
+                                          pid=os.getpid()))
     state = ens.state()
     if not np.isfinite(state).all():
         raise RuntimeError("non-finite state after the timed steps")
 
     if rank == 0:
+        elapsed = float(np.median(blocks))
+        stages = len(ens.tab.b) if ens.tab is not None else 1
         bytes_per_launch = sweep_bytes_per_node(model) * N * len(mine)
         achieved = bytes_per_launch / (sweep_ms / sweep_n * 1e-3) / 1e9 if sweep_n else None
-        traffic = None
+        step_bytes = step_bytes_per_node(model, scheme, stages) * N * len(mine)
+        step_gbs = step_bytes / elapsed * args.steps / 1e9
+        traffic, traffic_src = None, None
         tfile = os.path.join(ROOT, "profiles", "sweep_traffic.json")
         if os.path.exists(tfile) and args.config == 3 and args.members_per_gpu == 1 \
-                and not args.nodes:
+                and not args.nodes and scheme == "ROS2":
             with open(tfile) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+                tj = json.load(f)
+            traffic = tj.get("hbm_bytes_per_launch")
+            traffic_src = "profiles/sweep_traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE " \
+                          "passes of this command, not collected in this run" % tj.get("round", "r01")
         out = {
             "metric": "implicit time-steps/s, 1e6-node 3-var system (member-steps/s over all GPUs)",
             "value": n_members * args.steps / elapsed,
@@ -223,27 +279,46 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            "timing": {"repeats": len(blocks), "statistic": "median of the K-step blocks (max over ranks per block)",
+                       "block_ms_min": float(blocks.min()) * 1e3, "block_ms_max": float(blocks.max()) * 1e3},
             "config": {"workload": "BASELINE config %d: %s, N=%d nodes, %s, fixed dt=%g, %s"
                                    % (args.config, name, N,
                                       "periodic" if pars["periodic"] else "clamped", dt, scheme),
                        "members_per_gpu": args.members_per_gpu,
                        "parallelism": "ensemble members sharded by rank, no data-path collective",
                        "solver_levels": solver.describe()["chunks"]},
-            "roofline": {"bound": "hbm", "kernel": "tfk_sweep_fj",
+            "roofline": {"bound": "hbm", "kernel": sweep_kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic": traffic,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_ms": (sweep_ms / sweep_n) if sweep_n else None},
-            "kernels_ms_per_step": {k: round(v[0] / nprof, 5) for k, v in report.items()},
+            "roofline_step": {"bound": "hbm", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": step_gbs / HBM_PEAK_GBS,
+                              "algorithmic_bytes_per_step": step_bytes,
+                              "formula": "SURVEY 8(d) implicit-step bytes: %d B/node" %
+                                         step_bytes_per_node(model, scheme, stages)},
         }
-        if world == 1 and args.members_per_gpu == 1:
+        if report:
+            out["kernels_ms_per_step"] = {k: round(v[0] / nprof, 5) for k, v in report.items()}
+        if world > 1:
+            devices = [s["device"] for s in seen]
+            out["backend"] = "%s (%s)" % (backend, "RCCL over xGMI" if backend == "nccl" else "rehearsal")
+            out["ranks_seen"] = len(seen)
+            out["devices_seen"] = devices
+            out["members_per_rank"] = [s["members"] for s in seen]
+            out["steps_per_s_per_rank"] = [round(float(args.members_per_gpu * args.steps / np.median(r)), 2)
+                                           for r in per_rank]
+            if backend == "nccl" and len(set(devices)) != world:
+                raise RuntimeError("ranks share a GPU: %s" % devices)
+        if world == 1 and args.members_per_gpu == 1 and not args.plain:
             out["scheme_api_steps_per_s"] = scheme_api_rate(model, args.config, N, scheme, dt)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, N, scheme)
             out["cpu_baseline_fair"] = cpu_baseline(args.config, N, scheme, fair=True)
-            if args.cpu_workers > 1:
-                out["cpu_baseline_members"] = cpu_baseline(args.config, N, scheme, workers=args.cpu_workers)
+            workers = args.cpu_workers or (min(64, os.cpu_count() or 1) if args.members_per_gpu > 1 else 0)
+            if workers > 1:
+                out["cpu_baseline_members"] = cpu_baseline(args.config, N, scheme, workers=workers)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -132,8 +132,16 @@ int tf_step_theta(tf_solver*, int32_t src, int32_t dst, double dt, double theta)
 int tf_step_row(tf_solver*, int32_t src, int32_t dst, double dt, int32_t s,
                 const double* alpha, const double* gamma, const double* b,
                 const double* b_pred, int32_t hook_after, double* err_out);
+/* linearly implicit BDF-2 (new, scheme protocol of schemes.py:523-559); the history U_{n-1}
+ * is the solver's own: for a caller that owns the solver and steps one trajectory on it */
 int tf_step_bdf2(tf_solver*, int32_t src, int32_t dst, double dt);
 int tf_bdf2_reset(tf_solver*);
+/* the same step for scheme objects that share a solver: `owner` (non-zero) names the history
+ * buffer of one scheme instance, `continuing` != 0 says that slot `src` holds the state that
+ * owner's previous step produced; otherwise the step restarts in backward-Euler form */
+int tf_step_bdf2_owned(tf_solver*, int32_t src, int32_t dst, double dt, int64_t owner,
+                       int32_t continuing);
+int tf_bdf2_release(tf_solver*, int64_t owner);      /* frees that history buffer */
 /* ||state[a] - state[b]||_ord of every dependent variable, out[nsys][nvar]; ord = 2
  * or 0 (max norm): the error estimate of the step-doubling wrapper
  * (schemes.py:41-44) without bringing the fields to the host */

@@ -40,7 +40,7 @@ def build(model, parvec_mask=0, opt="-O1"):
         hdr = os.path.join(BUILD, "model_%s.h" % tag)
         with open(hdr, "w") as f:
             f.write(src)
-        cmd = ["g++", "-std=c++17", opt, "-g0", "-shared", "-fPIC", "-ffp-contract=off",
+        cmd = ["g++", "-std=c++17", *opt.split(), "-g0", "-shared", "-fPIC", "-ffp-contract=off",
                "-fno-fast-math", "-I", CSRC, "-I", os.path.join(ROOT, "include"),
                '-DTF_EMU_MODEL_HEADER="%s"' % hdr,
                os.path.join(CSRC, "tf_runtime.cpp"), os.path.join(HERE, "tf_backend_emu.cpp"),

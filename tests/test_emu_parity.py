@@ -55,6 +55,10 @@ def test_bdf2(backend):
     pc.check_bdf2(backend)
 
 
+def test_bdf2_interleaved(backend):
+    pc.check_bdf2_interleaved(backend)
+
+
 def test_simulation_golden(backend):
     pc.check_simulation_golden(backend)
 
@@ -86,6 +90,10 @@ def test_notebook_models(name, backend):
 
 def test_simulation_stays_resident(backend):
     pc.check_simulation_stays_resident(backend)
+
+
+def test_container_on_device_fields(backend, tmp_path):
+    pc.check_container_on_device_fields(backend, tmp_path)
 
 
 def test_unstable_factorisation_is_loud(backend):

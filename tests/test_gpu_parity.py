@@ -80,6 +80,10 @@ def test_bdf2():
     pc.check_bdf2(HIP)
 
 
+def test_bdf2_interleaved():
+    pc.check_bdf2_interleaved(HIP)
+
+
 def test_simulation_golden():
     pc.check_simulation_golden(HIP)
 
@@ -176,8 +180,95 @@ def test_full_size_step_properties(cfg):
     key = "U" if cfg == 2 else "h"
     before, after = np.asarray(fields[key]), np.asarray(new[key])
     assert np.isfinite(after).all()
-    assert abs(after.mean() - before.mean()) <= 1e-11 * max(1.0, abs(before).max())
+    drift = abs(after.mean() - before.mean())
+    assert drift <= 1e-11 * max(1.0, abs(before).max()), drift
     assert not np.array_equal(before, after)
+
+
+def test_full_size_step_config5():
+    """BASELINE config 5 at its full size (M5, N = 4e6, clamped, Dirichlet hook A[0] = A[-1] = 1,
+    dt = 1e-3): the backward-Euler start step and one two-step BDF-2 step.  Properties that do
+    not need the oracle at that size: finite, boundary values exact, the factorisation's
+    componentwise backward error at rounding level with no refinement, and -- the scheme being
+    linearly implicit -- the defining equation of each step holds for the result:
+        (I - c J(U_n)) (U_{n+1} - U_n) = rhs        checked with the device J @ v product."""
+    name, fd, pars, dt, sch = corpus.config_inputs(5)
+    assert sch == "BDF2" and fd["x"].size == 4 * 10 ** 6
+    m = pc.device_model(name, HIP)
+    hook = pc.DEVICE_HOOKS["cfg5"]
+    scheme = schemes.BDF2(m)
+    f0 = m.fields_template(**fd)
+    t1, f1 = scheme(0.0, f0, dt, pars, hook=hook)          # backward-Euler form
+    solver = f1._device_backing().stepper.solver
+    om1, refined1 = solver.backward_error()
+    t2, f2 = scheme(t1, f1, dt, pars, hook=hook)           # two-step form
+    om2, refined2 = solver.backward_error()
+    print("config 5 full size: backward error %.1e (BE step), %.1e (BDF-2 step)" % (om1, om2))
+    assert om1 < 1e-10 and om2 < 1e-10 and not refined1 and not refined2, (om1, om2)
+    u0 = np.array([np.asarray(fd[k]) for k in m._dep_vars])
+    u0[0, 0] = u0[0, -1] = 1.0                              # the hook at t = 0
+    u1 = np.array([np.asarray(f1[k]) for k in m._dep_vars])
+    u2 = np.array([np.asarray(f2[k]) for k in m._dep_vars])
+    for u in (u1, u2):
+        assert np.isfinite(u).all()
+        assert u[0, 0] == 1.0 and u[0, -1] == 1.0           # boundary values exact
+    assert not np.array_equal(u1, u2)
+    # defining equation of the second step, with the F and J the step itself evaluated
+    # (still resident: F planes and the J @ v kernel of the same solver)
+    N, nvar = fd["x"].size, m._nvar
+    flat = lambda u: u.T.reshape(-1)
+    F1 = solver.get_F()[0]
+    d2 = flat(u2) - flat(u1)
+    rhs = (flat(u1) - flat(u0)) / 3.0 + (2.0 / 3.0) * dt * F1
+    res = (d2 - (2.0 / 3.0) * dt * solver.matvec(d2)[0] - rhs).reshape(N, nvar)
+    # the two hooked nodes are overwritten after the solve, which also enters their
+    # neighbours' rows through J: leave nodes 0, 1, N-2, N-1 out
+    scale = np.abs(rhs).max()
+    worst = np.abs(res[2:-2]).max() / scale
+    print("config 5 full size: BDF-2 defining-equation residual %.1e (relative)" % worst)
+    assert worst <= 1e-10, worst
+
+
+def test_config4_shard_full_size():
+    """BASELINE config 4 per GPU: 8 members x N = 1e6 of the film model in one solver, with the
+    sweep's parameter table (c = 0.5 + m/64, We = 0.005 (1 + m mod 8), phase 2 pi m/64;
+    rank 3's members of the 64: m = 3, 11, ..., 59).  Finite, mean of h conserved per member,
+    and one member equals a single-member solver on the same inputs."""
+    import importlib.util, os
+    from triflow_amd.ensemble import Ensemble, shard_members
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    table = bench.member_table(64, None)[shard_members(64, 3, 8)]
+    assert table.shape == (8, 3)
+    name, x, fields, pars, dt, scheme = bench.build_problem(3, None, table)
+    assert x.size == 10 ** 6 and scheme == "ROS2" and fields["h"].shape == (8, 10 ** 6)
+    m = pc.device_model(name, HIP)
+    ens = Ensemble(m, x, fields, pars, True, scheme=scheme, nstate=2)
+    nsteps = 2
+    for _ in range(nsteps):
+        ens.step(dt)
+    ens.sync()
+    out = ens.state()                                        # [nvar][nsys][N]
+    ens.close()
+    assert np.isfinite(out).all()
+    for e in range(8):
+        drift = abs(out[0, e].mean() - fields["h"][e].mean())
+        assert drift <= 1e-11, (e, drift)
+    assert not np.array_equal(out[:, 0], out[:, 1])
+    e = 3
+    one = Ensemble(m, x, {k: v[e:e + 1] for k, v in fields.items()},
+                   dict(pars, c=pars["c"][e:e + 1], We=pars["We"][e:e + 1]), True,
+                   scheme=scheme, nstate=2)
+    for _ in range(nsteps):
+        one.step(dt)
+    one.sync()
+    ref = one.state()[:, 0, :]
+    one.close()
+    err = np.abs(ref - out[:, e, :]).max() / np.abs(ref).max()
+    print("config 4 shard: member %d vs single-member solver %.1e" % (e, err))
+    assert err <= 1e-10, err
 
 
 def test_step_doubling_device_norm():
@@ -189,14 +280,15 @@ def test_time_dependent_hook():
 
 
 # ---- BASELINE configurations against the oracle at sizes it still finishes in seconds ----
-@pytest.mark.parametrize("cfg,N,nsteps,tol", [(2, 10 ** 6, 2, 2e-8), (3, 2 * 10 ** 5, 2, 5e-7),
-                                              (5, 4 * 10 ** 5, 3, 1e-9)])
+@pytest.mark.parametrize("cfg,N,nsteps,tol", [(2, 10 ** 6, 2, 1e-7), (3, 2 * 10 ** 5, 2, 2.5e-10),
+                                              (5, 4 * 10 ** 5, 3, 2e-11)])
 def test_config_steps_vs_oracle(cfg, N, nsteps, tol):
     """Configs 2 (full size), 3 and 5 (1/5 and 1/10 size, same dx scaling rules as
     corpus.config_inputs): the configured scheme on the device against the oracle
-    (reference algorithm + SuperLU).  Tolerances: cond(A)*eps of the reference's own
-    solve: config 2 at N = 1e6 has cond(I - dt J) = 4e7 (measured 1.4e-9),
-    the film model reaches 2e10 at the full size."""
+    (reference algorithm + SuperLU).  Tolerances = 100 x the measured difference
+    (1.4e-9, 2.6e-12, 1.7e-13 on MI355X; the measured value is printed and shown on failure).
+    The differences are cond(A)*eps of the two direct solvers: config 2 at N = 1e6 has
+    cond(I - dt J) = 4e7."""
     from oracle import numpy_path as ora
     name, fd, pars, dt, sch = corpus.config_inputs(cfg, N)
     m, mo = pc.device_model(name, HIP), pc.oracle_model(name)
@@ -213,8 +305,8 @@ def test_config_steps_vs_oracle(cfg, N, nsteps, tol):
     u_d, u_o = f_d.uflat, f_o.uflat
     err = np.abs(u_d - u_o).max() / np.abs(u_o).max()
     print("config %d N=%d: rel err vs oracle %.2e, backward error %.1e" % (cfg, N, err, omega))
-    assert err <= tol, (cfg, err)
-    assert omega < 1e-10 and not refined
+    assert err <= tol, "config %d: rel err vs oracle %.3e > %.1e" % (cfg, err, tol)
+    assert omega < 1e-10 and not refined, (omega, refined)
 
 
 @pytest.mark.parametrize("name", sorted(pc.NOTEBOOK_CASES))
@@ -224,6 +316,14 @@ def test_notebook_models(name):
 
 def test_simulation_stays_resident():
     pc.check_simulation_stays_resident(HIP)
+
+
+def test_container_on_device_fields(tmp_path):
+    pc.check_container_on_device_fields(HIP, tmp_path)
+
+
+def test_model_load_reuses_code_object(tmp_path):
+    pc.check_model_load_reuses_code_object(HIP, tmp_path)
 
 
 def test_unstable_factorisation_is_loud():
@@ -237,13 +337,17 @@ def test_ensemble_equals_single_members():
     pc.check_ensemble_equals_single_members(HIP, N=3000, nsys=2, m1=8, m_upper=3)
 
 
-@pytest.mark.parametrize("cfg,N,sch", [(1, 200, "Theta"), (2, 20000, "Theta"), (3, 20000, "ROS2"),
-                                       (3, 20000, "RODASPR"), (5, 20000, "BDF2")])
-def test_hundred_step_drift(cfg, N, sch):
-    """Measured on MI355X: 1e-14 ... 2e-11 after 100 steps (tools/gpu_drift.py prints the table)."""
+@pytest.mark.parametrize("cfg,N,sch,tol1,tol100", [
+    (1, 200, "Theta", 7e-14, 1e-12), (2, 20000, "Theta", 7e-11, 7e-9), (3, 20000, "ROS2", 4e-13, 4e-12),
+    (3, 20000, "RODASPR", 4e-13, 8e-12), (5, 20000, "BDF2", 3e-14, 1e-12)])
+def test_hundred_step_drift(cfg, N, sch, tol1, tol100):
+    """Device path vs oracle after 1 / 100 steps; tolerances = 100 x the values measured on MI355X
+    (7e-16 / 1e-14, 7e-13 / 7e-11, 4e-15 / 4e-14, 4e-15 / 8e-14, 1e-16 / 1e-14; not below 100 eps);
+    tools/gpu_drift.py prints the table."""
     d = pc.drift_against_oracle(HIP, cfg, N, sch)
-    print("config %d N=%d %s: %.1e / %.1e / %.1e after 1 / 10 / 100 steps" % (cfg, N, sch, d[1], d[10], d[100]))
-    assert d[1] <= 1e-11 and d[100] <= 1e-9, d
+    msg = "config %d N=%d %s: %.1e / %.1e / %.1e after 1 / 10 / 100 steps" % (cfg, N, sch, d[1], d[10], d[100])
+    print(msg)
+    assert d[1] <= tol1 and d[100] <= tol100, msg
 
 
 @pytest.mark.parametrize("script,args", [("advection_diffusion.py", []), ("film_rosenbrock.py", ["20000"]),

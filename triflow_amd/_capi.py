@@ -66,6 +66,9 @@ SIGNATURES = {
                               c_double_p]),
     "tf_step_bdf2": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double]),
     "tf_bdf2_reset": (C.c_int, [C.c_void_p]),
+    "tf_step_bdf2_owned": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_int64,
+                                     C.c_int32]),
+    "tf_bdf2_release": (C.c_int, [C.c_void_p, C.c_int64]),
     "tf_diff_norm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_double_p]),
     "tf_backward_error": (C.c_int, [C.c_void_p, c_double_p, c_int32_p]),
     "tf_sync": (C.c_int, [C.c_void_p]),
@@ -318,8 +321,18 @@ class DeviceSolver:
                       int(hook_after), C.byref(err) if want_err else None)
         return np.float64(err.value) if (want_err and bp is not None) else None
 
-    def step_bdf2(self, src, dst, dt):
-        self.lib.call("tf_step_bdf2", self.handle, src, dst, float(dt))
+    def step_bdf2(self, src, dst, dt, owner=0, continuing=True):
+        """``owner`` 0: the solver's own history (a caller that owns the solver); otherwise the
+        history buffer of one scheme instance (``tf_step_bdf2_owned``)."""
+        if owner:
+            self.lib.call("tf_step_bdf2_owned", self.handle, src, dst, float(dt), int(owner),
+                          int(bool(continuing)))
+        else:
+            self.lib.call("tf_step_bdf2", self.handle, src, dst, float(dt))
+
+    def bdf2_release(self, owner):
+        if self.handle:
+            self.lib.call("tf_bdf2_release", self.handle, int(owner))
 
     def bdf2_reset(self):
         self.lib.call("tf_bdf2_reset", self.handle)

@@ -122,13 +122,17 @@ def build_code_object(model, parvec_mask=0, seg=None, sweep_block=None):
     waves = int(os.environ.get("TRIFLOW_SWEEP_WAVES", "0"))
     knobs = (_NT_STORE if nt else "") + ("#define TF_SWEEP_WAVES %d\n" % waves if waves else "")
     source = _TU_HEAD % knobs + body + _TU_TAIL
-    tag = codegen.source_hash(source, _skeleton_stamp(), " ".join(HIPCC_FLAGS), "elf")
+    tag = codegen.source_hash(source, _skeleton_stamp(), " ".join(HIPCC_FLAGS), hipcc_version(), "elf")
     os.makedirs(CACHE_DIR, exist_ok=True)
     hsaco = os.path.join(CACHE_DIR, "model_%s.hsaco" % tag)
     if not os.path.exists(hsaco):
         hip = os.path.join(CACHE_DIR, "model_%s.hip" % tag)
-        with open(hip, "w") as f:
+        # ranks of one node may compile the same uncached model at the same time: every
+        # file of the cache appears by rename, never half written
+        hip_tmp = hip + ".%d.tmp" % os.getpid()
+        with open(hip_tmp, "w") as f:
             f.write(source)
+        os.replace(hip_tmp, hip)
         tmp = hsaco + ".%d.tmp" % os.getpid()
         log.info("hipcc: compiling stencil + solver kernels for %s", model._diff_eqs)
 
@@ -152,11 +156,60 @@ def build_code_object(model, parvec_mask=0, seg=None, sweep_block=None):
                         model._diff_eqs, flags[0], spilled)
             flags = ["-O1"] + [f for f in flags if not f.startswith("-O")]
             usage = compile_with(flags)
-        with open(os.path.join(CACHE_DIR, "model_%s.json" % tag), "w") as f:
-            json.dump(dict(equations=list(model._diff_eqs), flags=flags, kernels=usage),
-                      f, indent=1)
+        meta = os.path.join(CACHE_DIR, "model_%s.json" % tag)
+        with open(meta + ".%d.tmp" % os.getpid(), "w") as f:
+            json.dump(dict(equations=list(model._diff_eqs), flags=flags, kernels=usage,
+                           skeleton=_skeleton_stamp(), hipcc=hipcc_version()), f, indent=1)
+        os.replace(meta + ".%d.tmp" % os.getpid(), meta)
         os.replace(tmp, hsaco)
+        evict_stale_cache()
     return hsaco, spec
+
+
+_hipcc_version = None
+
+
+def hipcc_version():
+    """First line of ``hipcc --version`` (part of the cache key: a code object is only
+    reused with the compiler that built it)."""
+    global _hipcc_version
+    if _hipcc_version is None:
+        try:
+            res = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True)
+            lines = [ln.strip() for ln in res.stdout.splitlines() if ln.strip()]
+            _hipcc_version = " / ".join(ln for ln in lines if "version" in ln.lower())[:200] or "unknown"
+        except OSError:
+            _hipcc_version = "unknown"
+    return _hipcc_version
+
+
+def evict_stale_cache(keep=()):
+    """Remove cached code objects that were built against another version of the kernel
+    skeleton (``csrc/*.h``) or another hipcc: they can never be selected again (the tag
+    hashes both), they only make the cache -- which travels with the package -- grow."""
+    if not os.path.isdir(CACHE_DIR):
+        return 0
+    stamp, ver, removed = _skeleton_stamp(), hipcc_version(), 0
+    for name in os.listdir(CACHE_DIR):
+        if not (name.startswith("model_") and name.endswith(".json")):
+            continue
+        base = os.path.join(CACHE_DIR, name[:-len(".json")])
+        try:
+            with open(base + ".json") as f:
+                meta = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if meta.get("skeleton") == stamp and meta.get("hipcc") == ver:
+            continue
+        if os.path.basename(base) in keep:
+            continue
+        for ext in (".hsaco", ".hip", ".json"):
+            try:
+                os.remove(base + ext)
+                removed += 1
+            except OSError:
+                pass
+    return removed
 
 
 class HipBackend:

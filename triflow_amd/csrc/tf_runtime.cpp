@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -105,7 +106,7 @@ struct tf_solver {
 
     std::vector<std::unique_ptr<DevBuf>> state;     // [nstate] x nvar planes
     DevBuf helpers, parvec, parsca, dx, xcoord;
-    DevBuf F, Jv, Wstage, Wsum, Wjv, Wrhs, Wres, Wdel, Uprev, K[TF_MAX_TERMS];
+    DevBuf F, Jv, Wstage, Wsum, Wjv, Wrhs, Wres, Wdel, K[TF_MAX_TERMS];
     DevBuf staging, normbuf;
     DevBuf red;            // reduction scalars
     int* status = nullptr;
@@ -131,9 +132,11 @@ struct tf_solver {
     char* poke_buf = nullptr;      // scratch of tf_poke
     size_t poke_bytes = 0;
 
-    // BDF-2 history
-    bool bdf_have_prev = false;
-    double bdf_dt_prev = 0.0;
+    // BDF-2 history U_{n-1}: one per scheme instance that steps on this solver ("owner";
+    // owner 0 is the solver's own buffer Uprev, used by callers that own the solver)
+    struct BdfHist { DevBuf Uprev; bool have_prev = false; double dt_prev = 0.0; };
+    BdfHist bdf0;
+    std::map<int64_t, std::unique_ptr<BdfHist>> bdf_owned;
 
     // timing
     uint32_t timing = 0;     // bit k: time launches of kernel k
@@ -599,7 +602,7 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
     if (sp.uses_x) s->xcoord.alloc(plane, tot); else s->xcoord.alloc(1, tot);
     s->F.alloc((size_t)sp.nvar * plane, tot);
     s->Jv.alloc((size_t)std::max(sp.nnz, 1) * plane, tot);
-    DevBuf* work[] = {&s->Wstage, &s->Wsum, &s->Wjv, &s->Wrhs, &s->Wres, &s->Wdel, &s->Uprev};
+    DevBuf* work[] = {&s->Wstage, &s->Wsum, &s->Wjv, &s->Wrhs, &s->Wres, &s->Wdel};
     for (DevBuf* w : work) w->alloc((size_t)sp.nvar * plane, tot);
     for (int i = 0; i < TF_MAX_TERMS; ++i) s->K[i].alloc(i < 6 ? (size_t)sp.nvar * plane : 1, tot);
     s->red.alloc(8, tot);
@@ -965,29 +968,58 @@ int tf_step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns,
 // Linearly implicit BDF-2 (not in the reference; DESIGN.md "BDF-2"):
 //   (I - 2/3 dt J)(U+ - U) = 1/3 (U - Uprev) + 2/3 dt F     with history
 //   (I -     dt J)(U+ - U) = dt F                           first step / dt changed
-int tf_step_bdf2(tf_solver* s, int32_t src, int32_t dst, double dt) {
-    TF_API_BEGIN
-    require(s, "null solver");
+}  // extern "C"
+namespace {
+void step_bdf2(tf_solver* s, int32_t src, int32_t dst, double dt, tf_solver::BdfHist& h, bool continuing) {
     require(src != dst, "tf_step_bdf2: src and dst slots must differ");
+    if (h.Uprev.n == 0) h.Uprev.alloc((size_t)s->vecn(), s->bytes);     // history buffers are made on first use
     double* U = s->st(dst);
     const double* Uin = s->stage_input(src, U);
-    const bool two_step = s->bdf_have_prev &&
-        std::fabs(s->bdf_dt_prev - dt) <= 1e-12 * std::fabs(dt);
+    const bool two_step = continuing && h.have_prev &&
+        std::fabs(h.dt_prev - dt) <= 1e-12 * std::fabs(dt);
     // rhs = 1/3 (U - Uprev) + 2/3 dt F (two-step) or dt F (first step), and Uprev <- U
-    s->sweep_bdf2(Uin, two_step, 1.0 / 3.0, two_step ? (2.0 / 3.0) * dt : dt, s->Wrhs.p, s->Uprev.p);
-    const double* rhs = s->Wrhs.p;
-    s->bdf_have_prev = true;
-    s->bdf_dt_prev = dt;
-    s->factor(two_step ? (2.0 / 3.0) * dt : dt, rhs, s->Wdel.p);
+    s->sweep_bdf2(Uin, two_step, 1.0 / 3.0, two_step ? (2.0 / 3.0) * dt : dt, s->Wrhs.p, h.Uprev.p);
+    h.have_prev = true;
+    h.dt_prev = dt;
+    s->factor(two_step ? (2.0 / 3.0) * dt : dt, s->Wrhs.p, s->Wdel.p);
     const double* ys[2] = {Uin, s->Wdel.p};
     s->vec(TF_VEC_ADD, U, nullptr, 2, ys, nullptr);
     s->apply_dirichlet(U, true);
+}
+}  // namespace
+extern "C" {
+int tf_step_bdf2(tf_solver* s, int32_t src, int32_t dst, double dt) {
+    TF_API_BEGIN
+    require(s, "null solver");
+    step_bdf2(s, src, dst, dt, s->bdf0, true);
+    TF_API_END
+}
+// The same step for a scheme object that shares the solver with others: `owner` names its
+// history (any non-zero id), `continuing` says that `src` is the state this owner's previous
+// step produced -- otherwise the step restarts with the backward-Euler form.
+int tf_step_bdf2_owned(tf_solver* s, int32_t src, int32_t dst, double dt, int64_t owner, int32_t continuing) {
+    TF_API_BEGIN
+    require(s, "null solver");
+    require(owner != 0, "tf_step_bdf2_owned: owner id 0 is the solver's own history (tf_step_bdf2)");
+    auto& slot = s->bdf_owned[owner];
+    if (!slot) slot.reset(new tf_solver::BdfHist());
+    step_bdf2(s, src, dst, dt, *slot, continuing != 0);
     TF_API_END
 }
 int tf_bdf2_reset(tf_solver* s) {
     TF_API_BEGIN
     require(s, "null solver");
-    s->bdf_have_prev = false;
+    s->bdf0.have_prev = false;
+    TF_API_END
+}
+int tf_bdf2_release(tf_solver* s, int64_t owner) {
+    TF_API_BEGIN
+    require(s, "null solver");
+    auto it = s->bdf_owned.find(owner);
+    if (it != s->bdf_owned.end()) {
+        tfb::stream_sync(s->stream);              // the buffer may still be read by a queued step
+        s->bdf_owned.erase(it);
+    }
     TF_API_END
 }
 

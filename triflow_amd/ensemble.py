@@ -60,8 +60,11 @@ class Ensemble:
                 v = np.broadcast_to(v, (self.nsys, self.N))
                 mask |= 1 << k
             values.append(v)
-        self.solver = cm.solver(self.N, periodic, self.nsys, mask, device=device,
-                                **solver_opts)
+        # a solver of its own (not the per-shape cache of CompiledModel.solver): two ensembles
+        # of the same shape must not share state slots, parameters or boundary data
+        from ._capi import DeviceSolver
+        self.solver = DeviceSolver(cm.device_model(mask, int(device)), self.N, nsys=self.nsys,
+                                   periodic=periodic, device=device, **solver_opts)
         s = self.solver
         s.set_dx((x[:, -1] - x[:, 0]) / (self.N - 1))
         s.set_x(x)
@@ -101,7 +104,14 @@ class Ensemble:
         self.t += dt
 
     def sync(self):
+        """Wait for the queued steps; raises if a factorisation met a singular pivot
+        block or lost accuracy (``RuntimeError``)."""
         self.solver.sync()
+
+    check = sync
+
+    def close(self):
+        self.solver.close()
 
     def state(self):
         """Dependent variables, ``[nvar][nsys][N]``."""

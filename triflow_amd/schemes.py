@@ -23,6 +23,7 @@ and arbitrary Python hooks are served.
 """
 
 import logging
+import weakref
 from functools import wraps
 
 import numpy as np
@@ -275,58 +276,86 @@ class BDF2:
 
         (I - 2/3 dt J(U_n)) (U_{n+1} - U_n) = 1/3 (U_n - U_{n-1}) + 2/3 dt F(U_n)
 
-    The first call, and any call whose ``dt`` differs from the previous one,
-    is the backward-Euler form ``(I - dt J)(U_{n+1} - U_n) = dt F``.  The
-    history ``U_{n-1}`` lives on the device next to the state."""
+    The first call, any call whose ``dt`` differs from the previous one, and any call
+    whose ``fields`` are not the container the previous call of *this* object returned
+    (a restart, another trajectory) is the backward-Euler form
+    ``(I - dt J)(U_{n+1} - U_n) = dt F``.  The history ``U_{n-1}`` lives on the device
+    and belongs to this scheme object: several BDF2 objects can step on the same model
+    (they share one ``tf_solver``) without seeing each other's history."""
+
+    _ids = iter(range(1, 2 ** 62))
 
     def __init__(self, model):
         self._model = model
-        self._stepper = None
+        self._owner = next(BDF2._ids)      # names this object's history buffer on the device
+        self._last = None                  # weak reference to the container last returned
+        self._solvers = []
 
     def __call__(self, t, fields, dt, pars, hook=null_hook):
+        continuing = self._last is not None and self._last() is fields
+
         def launch(solver, src, dst):
-            if self._stepper is not solver:
-                solver.bdf2_reset()
-                self._stepper = solver
-            solver.step_bdf2(src, dst, dt)
+            if not any(s is solver for s in self._solvers):
+                self._solvers.append(solver)
+            solver.step_bdf2(src, dst, dt, owner=self._owner, continuing=continuing)
         new, pars, _ = _device_step(self._model, t, fields, pars, hook, launch, dt=dt)
         if not _is_device_hook(hook):
             new, _ = hook(t + dt, new, pars)
+        try:
+            self._last = weakref.ref(new)
+        except TypeError:                  # a foreign container type without weak references
+            self._last = lambda new=new: new
         return t + dt, new
 
     def reset(self):
-        if self._stepper is not None:
-            self._stepper.bdf2_reset()
+        """Forget the history: the next call starts with the backward-Euler form."""
+        self._last = None
+
+    def __del__(self):
+        for solver in getattr(self, "_solvers", ()):
+            try:
+                solver.bdf2_release(self._owner)
+            except Exception:
+                pass
+
+
+class _HostOdeProblem:
+    """dU/dt = F(U) as SciPy's integrators want it: flat vectors in and out, evaluated by
+    the device-compiled ``model.F`` / ``model.J`` (seam #1, one PCIe round trip per call).
+    One instance per ``scipy_ode.__call__``: it owns the working container and the hook."""
+
+    def __init__(self, model, work, pars, hook):
+        self.model, self.work, self.pars, self.hook = model, work, pars, hook
+
+    def _state(self, t, U):
+        self.work.fill(U)
+        self.work, pars = self.hook(t, self.work, self.pars)
+        return self.work, pars
+
+    def rhs(self, t, U):
+        return self.model.F(*self._state(t, U))
+
+    def dense_jacobian(self, t, U):
+        return self.model.J(*self._state(t, U), sparse=False)
 
 
 class scipy_ode:
-    """Proxy around ``scipy.integrate.ode`` (``schemes.py:430-499``): the
-    integrator runs on the host and calls the device-evaluated ``model.F``
-    (and the dense ``model.J`` when ``jac=True``)."""
+    """Any ``scipy.integrate.ode`` integrator as a scheme (``schemes.py:430-499``; outside
+    the accelerated path: the integrator runs on the host, dense Jacobian when
+    ``jac=True``).  Kept so that scripts naming it keep running."""
 
     def __init__(self, model, jac=False, integrator="vode", **integrator_kwargs):
-        from scipy.integrate import ode
-
-        def func(t, U, fields, pars, hook):
-            fields.fill(U)
-            fields, pars = hook(t, fields, pars)
-            return model.F(fields, pars)
-
-        def jacob(t, U, fields, pars, hook):
-            fields.fill(U)
-            fields, pars = hook(t, fields, pars)
-            return model.J(fields, pars, sparse=False)
-
-        self._solv = ode(func, jac=jacob if jac else None)
-        self._solv.set_integrator(integrator, **integrator_kwargs)
+        self._model, self._use_jac = model, bool(jac)
+        self._integrator, self._options = integrator, dict(integrator_kwargs)
 
     def __call__(self, t, fields, dt, pars, hook=null_hook):
-        solv = self._solv
-        fields, pars = hook(t, fields, pars)
-        solv.set_initial_value(fields.uflat, t)
-        solv.set_f_params(fields, pars, hook)
-        solv.set_jac_params(fields, pars, hook)
-        U = solv.integrate(t + dt)
-        fields.fill(U)
-        fields, _ = hook(t + dt, fields, pars)
-        return t + dt, fields
+        from scipy.integrate import ode
+        start, pars = hook(t, fields, pars)
+        problem = _HostOdeProblem(self._model, start, pars, hook)
+        driver = ode(problem.rhs, problem.dense_jacobian if self._use_jac else None)
+        driver.set_integrator(self._integrator, **self._options)
+        driver.set_initial_value(start.uflat, t)
+        end = problem.work
+        end.fill(driver.integrate(t + dt))
+        end, _ = hook(t + dt, end, pars)
+        return t + dt, end
