@@ -142,6 +142,26 @@ int tf_bdf2_reset(tf_solver*);
 int tf_step_bdf2_owned(tf_solver*, int32_t src, int32_t dst, double dt, int64_t owner,
                        int32_t continuing);
 int tf_bdf2_release(tf_solver*, int64_t owner);      /* frees that history buffer */
+/* One trial of the reference's universal step-doubling controller (schemes.py:33-66; it wraps
+ * every scheme a Simulation builds, simulation.py:190-197) without a host round trip per
+ * sub-step: a coarse step m*dt (src -> coarse), `nfine` fine steps dt (src -> tmp -> dst ...,
+ * nfine even: the last one lands in dst; the reference's loop bound is the literal 10) and the
+ * norm of their difference, queued back to back; the call returns when the norms are on the
+ * host: err_out[system] = max_var ||coarse - dst||_ord / (m*m - 1), ord = 2 or 0 (max).
+ * The Dirichlet list of the solver is applied as in the single steps. */
+enum { TF_SCHEME_THETA = 0, TF_SCHEME_ROW = 1 };
+typedef struct tf_scheme {
+    int32_t kind;            /* TF_SCHEME_THETA / TF_SCHEME_ROW */
+    int32_t stages;          /* ROW: s */
+    double theta;            /* Theta */
+    const double* alpha;     /* ROW: [s][s] */
+    const double* gamma;     /* ROW: [s][s] */
+    const double* b;         /* ROW: [s] */
+    int32_t hook_after;      /* ROW: the extra hook call of the fixed-step __call__ */
+    int32_t reserved;
+} tf_scheme;
+int tf_step_doubling(tf_solver*, int32_t src, int32_t dst, int32_t tmp, int32_t coarse, double dt,
+                     int32_t m, int32_t nfine, const tf_scheme* scheme, int32_t ord, double* err_out);
 /* ||state[a] - state[b]||_ord of every dependent variable, out[nsys][nvar]; ord = 2
  * or 0 (max norm): the error estimate of the step-doubling wrapper
  * (schemes.py:41-44) without bringing the fields to the host */
@@ -159,6 +179,9 @@ int tf_sync(tf_solver*);            /* waits for the stream, reports device-side
 int tf_timing_enable(tf_solver*, int32_t mask);
 int tf_timing_reset(tf_solver*);
 int tf_timing_get(tf_solver*, int32_t kernel, double* total_ms, int64_t* launches);
+/* diagnostic kernel builds (-DTF_STAMPS): shader-clock stamps of one workgroup per solver
+ * level, out[level][64]; the first call only switches the recording on */
+int tf_debug_stamps(tf_solver*, uint64_t* out, int32_t max_levels);
 int tf_kernel_count(void);
 const char* tf_kernel_name(int32_t kernel);
 

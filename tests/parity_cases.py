@@ -349,6 +349,53 @@ def check_step_doubling_device_norm(backend):
     assert np.allclose(n_dev_inf, [np.abs(np.asarray(fb["U"]) - np.asarray(fc["U"])).max()], rtol=0)
 
 
+def check_fused_step_doubling(backend):
+    """Row f1: a trial of the step-doubling controller as one device call
+    (tf_step_doubling: coarse step + ten fine steps + norm, one host wait) gives the bits of
+    the same trial driven step by step from Python, for Theta and a fixed-step Rosenbrock
+    scheme, with and without a constant Dirichlet hook; and it really is one call."""
+    from triflow_amd import _capi
+    cases = [("M2_diff", 80, True, lambda m: schemes.Theta(m), None, 0.05),
+             ("M1_advdiff", 64, False, lambda m: schemes.Theta(m, theta=0.5), "cfg1", 0.5),
+             ("M3_film", 48, True, lambda m: schemes.ROS2(m), None, 1e-3)]
+    for mname, N, periodic, make, hook, dt in cases:
+        m = device_model(mname, backend)
+        fd = corpus.synthetic_fields(mname, N, seed=4, periodic=periodic)
+        pars = corpus.synthetic_pars(mname, N, periodic)
+        kw = dict(hook=DEVICE_HOOKS[hook]) if hook else {}
+        out, calls = [], []
+        for fused in (True, False):
+            counts = dict(single=0, doubling=0)
+            orig = {k: getattr(_capi.DeviceSolver, k) for k in ("step_theta", "step_row", "step_doubling")}
+
+            def counted(name, key):
+                def f(self, *a, **k):
+                    counts[key] += 1
+                    return orig[name](self, *a, **k)
+                return f
+            _capi.DeviceSolver.step_theta = counted("step_theta", "single")
+            _capi.DeviceSolver.step_row = counted("step_row", "single")
+            _capi.DeviceSolver.step_doubling = counted("step_doubling", "doubling")
+            saved = schemes._fused_trial
+            if not fused:
+                schemes._fused_trial = lambda *a, **k: None
+            try:
+                scheme = schemes.time_stepping(make(m), tol=1e-2)
+                f, t = m.fields_template(**fd), 0.0
+                for _ in range(3):
+                    t, f = scheme(t, f, dt, pars, **kw)
+                out.append((t, f.uflat.copy()))
+            finally:
+                schemes._fused_trial = saved
+                for k, v in orig.items():
+                    setattr(_capi.DeviceSolver, k, v)
+            calls.append(counts)
+        assert out[0][0] == out[1][0], (mname, out[0][0], out[1][0])
+        assert np.array_equal(out[0][1], out[1][1]), mname
+        assert calls[0]["doubling"] >= 1 and calls[1]["doubling"] == 0, calls
+        assert calls[1]["single"] >= calls[0]["single"] + 11 * calls[0]["doubling"], calls
+
+
 def check_time_dependent_hook(backend):
     """Time-dependent Dirichlet data and a time-dependent parameter, served on
     the device by a declarative hook, against the oracle running the same hook as

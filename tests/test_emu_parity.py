@@ -79,6 +79,10 @@ def test_step_doubling_device_norm(backend):
     pc.check_step_doubling_device_norm(backend)
 
 
+def test_fused_step_doubling(backend):
+    pc.check_fused_step_doubling(backend)
+
+
 def test_time_dependent_hook(backend):
     pc.check_time_dependent_hook(backend)
 

@@ -53,11 +53,14 @@ if len(sys.argv) > 1 and sys.argv[1] == "one":
     A = sps.identity(n, format="csc") - c * Jo
     rhs = rng.standard_normal(n)
     xs = spla.spsolve(A, rhs)
-    s = pc.bound_solver(m, fd, pars, refine=0)
-    s.eval(0, with_j=True)
-    s.factor(c)
-    xx = s.solve(rhs)[0]
-    print("%.3e" % (np.abs(xx - xs).max() / np.abs(xs).max()))
+    errs = []
+    for opts in (dict(), dict(m1=8, m_upper=4), dict(m1=10 ** 6)):      # the plans of gpu_wide_model_check2.py
+        s = pc.bound_solver(m, fd, pars, refine=0, **opts)
+        s.eval(0, with_j=True)
+        s.factor(c)
+        xx = s.solve(rhs)[0]
+        errs.append("%.2e" % (np.abs(xx - xs).max() / np.abs(xs).max()))
+    print(" ".join(errs))
 else:
     from triflow_amd import compilers
     h3, u3 = build("-O3")

@@ -1,0 +1,35 @@
+"""In-kernel phase timing of the reduced-level factorisation (diagnostic build -DTF_STAMPS):
+shader-clock stamps of one workgroup per level, printed as cycles per phase."""
+import os, sys
+os.environ["TRIFLOW_HIPCC_EXTRA"] = (os.environ.get("TRIFLOW_HIPCC_EXTRA", "") + " -DTF_STAMPS").strip()
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import importlib.util
+spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+from triflow_amd import Model, workloads
+from triflow_amd.ensemble import Ensemble
+
+members = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+table = bench.member_table(members, None)
+name, x, fields, pars, dt, scheme = bench.build_problem(3, None, table)
+model = Model(*workloads.model_args(name))
+ens = Ensemble(model, x, fields, pars, True, scheme=scheme, nstate=2)
+s = ens.solver
+s.debug_stamps()                     # switch on
+for _ in range(5):
+    ens.step(dt)
+ens.sync()
+st = s.debug_stamps().astype(np.int64)
+print("levels", s.describe()["chunks"])
+for l in range(1, len(s.describe()["chunks"])):
+    r = st[l]
+    if r[0] == 0:
+        continue
+    total, real = r[21] - r[0], (r[31] - r[30]) / 100.0        # s_memrealtime: 100 MHz
+    marks = [r[0], r[1]] + [v for v in r[2:20] if v] + [r[20], r[21]]
+    d = np.diff(marks)
+    print("level %d: %d cycles = %.2f us (clock %.2f GHz)  load %d | rounds (A, B): %s | share %d | fold/end %d"
+          % (l + 1, total, real, total / real / 1e3 if real else 0, d[0],
+             " ".join("(%d, %d)" % (d[1 + 2 * i], d[2 + 2 * i]) for i in range((len(d) - 3) // 2)), d[-2], d[-1]))

@@ -27,6 +27,12 @@ class SolverOpts(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class Scheme(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("stages", C.c_int32), ("theta", C.c_double),
+                ("alpha", c_double_p), ("gamma", c_double_p), ("b", c_double_p),
+                ("hook_after", C.c_int32), ("reserved", C.c_int32)]
+
+
 #: name -> (restype, argtypes); every symbol declared in include/triflow_hip.h
 SIGNATURES = {
     "tf_last_error": (C.c_char_p, []),
@@ -70,11 +76,14 @@ SIGNATURES = {
                                      C.c_int32]),
     "tf_bdf2_release": (C.c_int, [C.c_void_p, C.c_int64]),
     "tf_diff_norm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_double_p]),
+    "tf_step_doubling": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double,
+                                   C.c_int32, C.c_int32, C.POINTER(Scheme), C.c_int32, c_double_p]),
     "tf_backward_error": (C.c_int, [C.c_void_p, c_double_p, c_int32_p]),
     "tf_sync": (C.c_int, [C.c_void_p]),
     "tf_timing_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "tf_timing_reset": (C.c_int, [C.c_void_p]),
     "tf_timing_get": (C.c_int, [C.c_void_p, C.c_int32, c_double_p, c_int64_p]),
+    "tf_debug_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int32]),
     "tf_kernel_count": (C.c_int, []),
     "tf_kernel_name": (C.c_char_p, [C.c_int32]),
 }
@@ -337,6 +346,22 @@ class DeviceSolver:
     def bdf2_reset(self):
         self.lib.call("tf_bdf2_reset", self.handle)
 
+    def step_doubling(self, src, dst, tmp, coarse, dt, m, desc, ord=2, nfine=10):
+        """One step-doubling trial (``tf_step_doubling``); ``desc``: dict(kind="theta", theta=..)
+        or dict(kind="row", alpha=.., gamma=.., b=.., hook_after=..).  Returns err per system."""
+        keep = []
+        if desc["kind"] == "theta":
+            sch = Scheme(0, 0, float(desc["theta"]), None, None, None, 0, 0)
+        else:
+            arrs = [_f64(desc[k]) for k in ("alpha", "gamma", "b")]
+            keep.extend(arrs)
+            sch = Scheme(1, arrs[2].size, 0.0, _dptr(arrs[0]), _dptr(arrs[1]), _dptr(arrs[2]),
+                         int(bool(desc.get("hook_after", True))), 0)
+        err = np.empty(self.nsys)
+        self.lib.call("tf_step_doubling", self.handle, src, dst, tmp, coarse, float(dt), int(m),
+                      int(nfine), C.byref(sch), 0 if ord in (0, np.inf, "inf") else int(ord), _dptr(err))
+        return err
+
     def diff_norms(self, slot_a, slot_b, ord=2):
         """||state[a] - state[b]|| per system and dependent variable, [nsys][nvar]."""
         out = np.empty((self.nsys, self.nvar))
@@ -352,6 +377,12 @@ class DeviceSolver:
 
     def sync(self):
         self.lib.call("tf_sync", self.handle)
+
+    def debug_stamps(self, levels=8):
+        """[levels][64] uint64 stamps of a -DTF_STAMPS kernel build (first call: switch on)."""
+        out = np.zeros((levels, 64), dtype=np.uint64)
+        self.lib.call("tf_debug_stamps", self.handle, out.ctypes.data_as(C.POINTER(C.c_uint64)), levels)
+        return out
 
     # ------------------------------------------------------------- measurement
     def timing(self, on=True, kernels=None):

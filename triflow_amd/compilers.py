@@ -41,10 +41,12 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "lib", "libtriflow_hip.so")
 CACHE_DIR = os.path.join(PKG_DIR, "_cache")
 GPU_ARCH = "gfx950"
+# TRIFLOW_HIPCC_EXTRA: e.g. "-DTF_CR_V2=0 -DTF_BACKSUB_DEPTH=1" (A/B runs of kernel variants)
 HIPCC_FLAGS = [*os.environ.get("TRIFLOW_HIPCC_OPT", "-O3").split(), "-std=c++17",
-               "-ffp-contract=off", "--offload-arch=" + GPU_ARCH]
+               "-ffp-contract=off", "--offload-arch=" + GPU_ARCH,
+               *os.environ.get("TRIFLOW_HIPCC_EXTRA", "").split()]
 
-_SKELETON = ("tf_args.h", "tf_math.h", "tf_kernels.h", "tf_coop_hip.h", "tf_entry_hip.h")
+_SKELETON = ("tf_args.h", "tf_math.h", "tf_kernels.h", "tf_coop_hip.h", "tf_cr2_hip.h", "tf_entry_hip.h")
 _TU_HEAD = ('#include <hip/hip_runtime.h>\n'
             '#define TF_DEVICE __device__ __forceinline__\n'
             '%s'

@@ -178,6 +178,8 @@ struct TfLevelArgs {
     int fold_top;
     double* topAinv;               // [b][b] planes over systems (TfTopArgs::Ainv)
     double* topx;                  // [sys][b]
+    // diagnostic builds (-DTF_STAMPS): one workgroup writes s_memtime stamps here (else NULL)
+    unsigned long long* stamps;
 };
 
 struct TfTopArgs {                 // final 1-node system per ensemble member

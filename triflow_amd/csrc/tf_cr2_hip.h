@@ -1,0 +1,682 @@
+// Cyclic-reduction factorisation of a reduced-level chunk, second version (3 <= b <= 8).
+//
+// Same algorithm, task lists, stored quantities (a.crf, a.zt) and outputs as
+// tfk_cr_factor_coop (tf_coop_hip.h) -- the solve kernels tfk_cr_fwd / tfk_cr_bwd read what
+// either writes -- but built around the latency of one round, which is what these levels
+// cost (one wavefront per chunk, 4 rounds of dependent block inversions):
+//   * Gauss-Jordan on the augmented row [D | I | L | U | y] of the node that goes: the
+//     lane ends with its rows of D^-1, E = D^-1 L, F = D^-1 U and z = D^-1 y, no product
+//     phase after the inversion;
+//   * the pivot lane of a step is found with three DPP max steps inside the 8-lane group
+//     (key = float magnitude with the lane number in its low bits), not through LDS, and
+//     only that lane publishes its row: one LDS round trip of 4b+1 doubles per pivot;
+//   * the chain lives in LDS as records per (position, block row) with a stride chosen
+//     against bank conflicts, ~20 KB per chunk instead of 36: two wavefronts per SIMD.
+// HIP only.
+#pragma once
+
+// Row / position strides (in doubles) of the chain in LDS.  Every access is 8 bytes wide,
+// i.e. LDS has 32 double-wide banks for the 32 lanes of a half wavefront; the strides are
+// the ones for which the access patterns of all rounds (own row of the nodes that go, rows of
+// the updated neighbours, broadcast reads of E / F / z) hit distinct banks: average conflict
+// degree 1.01 - 1.04, worst 2 (searched over RS <= RW + 3, PS <= b*RS + 15; the natural
+// [pos][4][b][b] image of the first version is 4- to 8-way).
+template <int BB> struct TfCr2Stride;
+template <> struct TfCr2Stride<3> { static constexpr int RS = 11, PS = 38; };
+template <> struct TfCr2Stride<4> { static constexpr int RS = 13, PS = 54; };
+template <> struct TfCr2Stride<5> { static constexpr int RS = 17, PS = 93; };
+template <> struct TfCr2Stride<6> { static constexpr int RS = 19, PS = 121; };
+template <> struct TfCr2Stride<7> { static constexpr int RS = 23, PS = 166; };
+template <> struct TfCr2Stride<8> { static constexpr int RS = 25, PS = 202; };
+
+template <int BB> struct TfCr2 {
+    static constexpr int G = 8, NGRP = 8, MAXLEN = TF_CR_MAXLEN, NPOS = MAXLEN + 1;
+    static constexpr int RW = 3 * BB + 1;                 // L | D | U | y of one block row
+    static constexpr int RS = TfCr2Stride<BB>::RS;        // row stride
+    static constexpr int PS = TfCr2Stride<BB>::PS;        // position stride
+    static constexpr int XW = 4 * BB + 1;                 // published pivot row
+    static constexpr int oL = 0, oD = BB, oU = 2 * BB, oY = 3 * BB;
+    static_assert(RS >= RW && PS >= BB * RS, "strides");
+};
+
+// max over the 8 lanes of a group (lanes 8q .. 8q+7 of the wavefront), result in every lane
+__device__ __forceinline__ unsigned tf_group8_max(unsigned v) {
+    unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    v = o > v ? o : v;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);            // quad_perm [2,3,0,1]
+    v = o > v ? o : v;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);           // row_half_mirror
+    return o > v ? o : v;
+}
+
+// Gauss-Jordan with partial pivoting on [S | A] shared by the 8 lanes of a group: lane g
+// enters with row g (S: the b x b block, A: NA augmented columns) and leaves with row `myk`
+// (returned) of [I | S^-1 A].  Rows are never moved; the unused lane with the largest
+// |S[.][k]| (as float; the lowest lane on ties) serves pivot k and publishes its row
+// through `xch` ([2][XW] doubles of this group, double buffered).
+template <int BB, int NA, int XW>
+__device__ __forceinline__ int tf_gj_aug(double (&S)[BB], double (&A)[NA], bool on, int g,
+                                         double* xch, bool& ok) {
+    static_assert(BB + NA <= XW, "exchange row too short");
+    int myk = -1;
+#pragma unroll
+    for (int kk = 0; kk < BB; ++kk) {
+        unsigned key = 0;
+        if (on && myk < 0) {
+            const float mag = (float)tf_abs(S[kk]);
+            unsigned bits = __float_as_uint(mag);
+            if (bits == 0 && S[kk] != 0.0) bits = 8;               // underflow is not a zero pivot
+            if (mag != mag) bits = 0x7f800000u;                    // NaN: taken, reported through ok
+            key = (bits & ~7u) | (unsigned)(7 - g);
+        }
+        const unsigned best = tf_group8_max(key);
+        const bool mine = on && myk < 0 && key == best;
+        double* buf = xch + (kk & 1) * XW;
+        if (mine) {
+#pragma unroll
+            for (int c = 0; c < BB; ++c) buf[c] = S[c];
+#pragma unroll
+            for (int c = 0; c < NA; ++c) buf[BB + c] = A[c];
+        }
+        __syncthreads();
+        const double pv = buf[kk];
+        if (on) ok = ok && (pv != 0.0) && tf_finite(pv);
+        const double rp = 1.0 / pv;
+        if (mine) myk = kk;
+        const double f2 = mine ? 0.0 : -S[kk] * rp;
+#pragma unroll
+        for (int c = 0; c < BB; ++c) S[c] = tf_fma(f2, buf[c], S[c]);
+#pragma unroll
+        for (int c = 0; c < NA; ++c) A[c] = tf_fma(f2, buf[BB + c], A[c]);
+        if (mine) {
+#pragma unroll
+            for (int c = 0; c < BB; ++c) S[c] *= rp;
+#pragma unroll
+            for (int c = 0; c < NA; ++c) A[c] *= rp;
+        }
+    }
+    return myk;
+}
+
+template <int BB>
+__device__ __forceinline__ void tfk_cr_factor_v2(const TfLevelArgs& a) {
+    typedef TfCr2<BB> C;
+    constexpr int G = C::G, NGRP = C::NGRP, NPOS = C::NPOS, B2 = BB * BB, REC = 4 * B2;
+    constexpr int RS = C::RS, PS = C::PS, XW = C::XW, NA = 3 * BB + 1;
+    constexpr int oL = C::oL, oD = C::oD, oU = C::oU, oY = C::oY;
+    const TfLayout& L = a.L;
+    const TfCrChunk<BB> ch(L);
+    const int tid = threadIdx.x, grp = tid / G, g = tid % G;
+    const bool row_on = g < BB;
+    const int gq = row_on ? g : 0;
+    const int mI = ch.mI, pe = ch.pe, len = ch.len;
+    const bool with_rhs = a.cr_rhs != 0;
+
+    __shared__ double sRow[NPOS * PS];
+    __shared__ double sX[NGRP * 2 * XW];
+    auto row = [&](int pos, int r) { return sRow + pos * PS + r * RS; };
+
+    TF_STAMP_REAL(a, 30);
+    TF_STAMP(a, 0);
+    // ---- load: records [node][L, D, U, second part of D][b][b] of a chunk are contiguous
+    {
+        const double* src = a.Ablk + (ch.nbase + ch.start) * REC;
+        const int n3 = len * 3 * B2;
+#pragma unroll 4
+        for (int i = tid; i < n3; i += 64) {
+            const int nd = i / (3 * B2), rem = i - nd * 3 * B2;
+            const int blk = rem / B2, rc = rem - blk * B2, r = rc / BB, c = rc - r * BB;
+            double v = src[nd * REC + blk * B2 + rc];
+            if (blk == 1) v += src[nd * REC + 3 * B2 + rc];        // D = both parts
+            row(nd + 1, r)[blk * BB + c] = v;
+        }
+        // position 0: the separator above; only its U block couples into this chunk
+        const double* prev = a.Ablk + (ch.nbase + ch.gprev) * REC + 2 * B2;
+        for (int i = tid; i < 3 * B2; i += 64) {
+            const int blk = i / B2, rc = i - blk * B2, r = rc / BB, c = rc - r * BB;
+            row(0, r)[blk * BB + c] = (blk == 2 && ch.has_prev) ? prev[rc] : 0.0;
+        }
+        const double* ys = a.rhs + (ch.nbase + ch.start) * 2 * BB;
+        for (int i = tid; i < (len + 1) * BB; i += 64) {
+            const int pos = i / BB, r = i - pos * BB;
+            row(pos, r)[oY] = (with_rhs && pos > 0) ? ys[(pos - 1) * 2 * BB + r] + ys[(pos - 1) * 2 * BB + BB + r] : 0.0;
+        }
+    }
+    __syncthreads();
+    if (!L.periodic) {                               // no neighbour beyond the ends of a system
+        if (ch.start == 0 && tid < B2) row(1, tid / BB)[oL + tid % BB] = 0.0;
+        if (ch.start + len == L.N && tid < B2) row(pe, tid / BB)[oU + tid % BB] = 0.0;
+        __syncthreads();
+    }
+
+    bool ok = true;
+    double* xch = sX + grp * 2 * XW;
+    TF_STAMP(a, 1);
+    int stamp_i = 2;
+    for (int s = 1; s <= mI; s <<= 1) {
+        // ---- phase A: the nodes k = s * (2 grp + 1) go; lane g takes row g of [D | I L U y]
+        const int nA = (mI / s + 1) / 2;             // <= 8: one per group
+        {
+            const bool on = grp < nA && row_on;
+            const int k = grp < nA ? s * (2 * grp + 1) : 1;
+            const double* rk = row(k, gq);
+            double S[BB], A[NA];
+#pragma unroll
+            for (int c = 0; c < BB; ++c) {
+                S[c] = rk[oD + c];
+                A[c] = c == g ? 1.0 : 0.0;
+                A[BB + c] = rk[oL + c];
+                A[2 * BB + c] = rk[oU + c];
+            }
+            A[3 * BB] = rk[oY];
+            const int myk = tf_gj_aug<BB, NA, XW>(S, A, on, g, xch, ok);
+            // A = rows myk of D^-1 | E | F | z
+            if (on) {
+                double* rec = a.crf + (ch.nbase + ch.node(k)) * 5 * B2 + myk * BB;
+                double* dst = row(k, myk);
+#pragma unroll
+                for (int c = 0; c < BB; ++c) {
+                    rec[0 * B2 + c] = A[c];
+                    rec[1 * B2 + c] = A[BB + c];
+                    rec[2 * B2 + c] = A[2 * BB + c];
+                    dst[oL + c] = A[BB + c];
+                    dst[oU + c] = A[2 * BB + c];
+                }
+                dst[oY] = A[3 * BB];
+                if (with_rhs) a.zt[(ch.nbase + ch.node(k)) * BB + myk] = A[3 * BB];
+            }
+        }
+        __syncthreads();
+        TF_STAMP(a, stamp_i); ++stamp_i;
+        // ---- phase B: the neighbours take the update, one task per group.  Interior
+        //      a = 2s(t+1): its L side lost kL = a-s, its U side loses kR = a+s (if there).
+        //      Last task: the L side of the own separator (pe) and the U side of position 0.
+        const int nB = mI / (2 * s);                 // <= 7
+        if (row_on && grp <= nB) {
+            const bool ends = grp == nB;
+            const int aa = 2 * s * (grp + 1), nq = mI / s;
+            const int aL = ends ? pe : aa, aU = ends ? 0 : aa;
+            const bool vL = ends ? (nq & 1) != 0 : true;
+            const bool vR = ends ? true : aa + s <= mI;
+            const int kL = ends ? nq * s : aa - s, kR = ends ? s : aa + s;
+            const int kLs = vL ? kL : 1, kRs = vR ? kR : 1;
+            double* rowL = row(aL, g);
+            double* rowU = row(aU, g);
+            double Lr[BB], Ur[BB];
+#pragma unroll
+            for (int c = 0; c < BB; ++c) { Lr[c] = rowL[oL + c]; Ur[c] = rowU[oU + c]; }
+            if (vL) {
+                double* rec = a.crf + (ch.nbase + ch.node(kL)) * 5 * B2 + 4 * B2 + g * BB;
+#pragma unroll
+                for (int c = 0; c < BB; ++c) rec[c] = Lr[c];
+            }
+            if (vR) {
+                double* rec = a.crf + (ch.nbase + ch.node(kR)) * 5 * B2 + 3 * B2 + g * BB;
+#pragma unroll
+                for (int c = 0; c < BB; ++c) rec[c] = Ur[c];
+            }
+            // the two sides one after the other (not interleaved): half the live registers
+            {
+                double nl[BB], dl[BB], yl = 0.0;
+#pragma unroll
+                for (int c = 0; c < BB; ++c) { nl[c] = 0.0; dl[c] = 0.0; }
+#pragma unroll
+                for (int m = 0; m < BB; ++m) {
+                    const double* eL = row(kLs, m);
+#pragma unroll
+                    for (int c = 0; c < BB; ++c) {
+                        nl[c] = tf_fma(-Lr[m], eL[oL + c], nl[c]);      // -L E_kL
+                        dl[c] = tf_fma(-Lr[m], eL[oU + c], dl[c]);      // -L F_kL
+                    }
+                    yl = tf_fma(-Lr[m], eL[oY], yl);
+                }
+                if (vL) {
+#pragma unroll
+                    for (int c = 0; c < BB; ++c) { rowL[oL + c] = nl[c]; rowL[oD + c] += dl[c]; }
+                    rowL[oY] += yl;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                double nu[BB], du[BB], yu = 0.0;
+#pragma unroll
+                for (int c = 0; c < BB; ++c) { nu[c] = 0.0; du[c] = 0.0; }
+#pragma unroll
+                for (int m = 0; m < BB; ++m) {
+                    const double* eR = row(kRs, m);
+#pragma unroll
+                    for (int c = 0; c < BB; ++c) {
+                        nu[c] = tf_fma(-Ur[m], eR[oU + c], nu[c]);      // -U F_kR
+                        du[c] = tf_fma(-Ur[m], eR[oL + c], du[c]);      // -U E_kR
+                    }
+                    yu = tf_fma(-Ur[m], eR[oY], yu);
+                }
+                if (vR) {
+#pragma unroll
+                    for (int c = 0; c < BB; ++c) { rowU[oU + c] = nu[c]; rowU[oD + c] += du[c]; }
+                    rowU[oY] += yu;
+                }
+            }
+        }
+        __syncthreads();
+        TF_STAMP(a, stamp_i); ++stamp_i;
+    }
+
+    // ---- this chunk's share of the next level's rows
+    if (row_on && grp < 2) {
+        const int nn = grp == 0 ? ch.p : ch.pprev;
+        double* rec = a.Anext + ((int64_t)ch.e * a.Lnext.N + nn) * REC;
+        double* rr = a.rhsnext + ((int64_t)ch.e * a.Lnext.N + nn) * 2 * BB;
+        if (grp == 0) {
+            const double* r = row(pe, g);
+#pragma unroll
+            for (int c = 0; c < BB; ++c) { rec[0 * B2 + g * BB + c] = r[oL + c]; rec[1 * B2 + g * BB + c] = r[oD + c]; }
+            if (with_rhs) rr[g] = r[oY];
+        } else {
+            const double* r = row(0, g);
+#pragma unroll
+            for (int c = 0; c < BB; ++c) { rec[2 * B2 + g * BB + c] = r[oU + c]; rec[3 * B2 + g * BB + c] = r[oD + c]; }
+            if (with_rhs) rr[BB + g] = r[oY];
+        }
+    }
+    TF_STAMP(a, 20);
+    if (a.fold_top) {
+        // one chunk per system: what is left of rows 0 and pe couples the separator to
+        // itself only (TfTopArgs): invert their sum here, and solve for the first rhs
+        __syncthreads();
+        const bool on = grp == 0 && row_on;
+        const double* r0 = row(0, gq);
+        const double* rp = row(pe, gq);
+        double S[BB], A[BB + 1];
+#pragma unroll
+        for (int c = 0; c < BB; ++c) {
+            S[c] = rp[oL + c] + rp[oD + c] + r0[oU + c] + r0[oD + c];
+            A[c] = c == g ? 1.0 : 0.0;
+        }
+        A[BB] = rp[oY] + r0[oY];
+        const int myk = tf_gj_aug<BB, BB + 1, XW>(S, A, on, g, xch, ok);
+        if (on) {
+            const int nsys = L.Ptot;                 // P == 1
+#pragma unroll
+            for (int c = 0; c < BB; ++c) a.topAinv[(int64_t)(myk * BB + c) * nsys + ch.e] = A[c];
+        }
+        if (with_rhs) {
+            // ... and the back-substitution of this level (tfk_cr_bwd_coop): E_k, F_k and z_k
+            // are still in LDS; the y slots take the solution
+            __syncthreads();
+            if (on) {
+                const double x = A[BB];
+                a.topx[(int64_t)ch.e * BB + myk] = x;
+                a.x[(ch.nbase + ch.node(pe)) * BB + myk] = x;
+                row(pe, myk)[oY] = x;
+                row(0, myk)[oY] = ch.has_prev ? x : 0.0;
+            }
+            __syncthreads();
+            int s = 1;
+            while (2 * s <= mI) s <<= 1;
+            for (; s >= 1; s >>= 1) {
+                const int nA = (mI / s + 1) / 2;
+                if (grp < nA && row_on) {
+                    const int k = s * (2 * grp + 1);
+                    const int kl = k - s, kr = k + s <= mI ? k + s : pe;
+                    double* rk = row(k, g);
+                    double xk = rk[oY];
+#pragma unroll
+                    for (int m = 0; m < BB; ++m) {
+                        xk = tf_fma(-rk[oL + m], row(kl, m)[oY], xk);
+                        xk = tf_fma(-rk[oU + m], row(kr, m)[oY], xk);
+                    }
+                    // every lane of the group reads the neighbours' y before any lane of
+                    // another group overwrites them: positions written in this round (k) are
+                    // never read in it (kl, kr belong to later rounds)
+                    rk[oY] = xk;
+                    a.x[(ch.nbase + ch.node(k)) * BB + g] = xk;
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (!ok) *a.status = 1;
+    TF_STAMP(a, 21);
+    TF_STAMP_REAL(a, 31);
+}
+
+// ===========================================================================
+// Third version: one WAVEFRONT per node of the round, 8 wavefronts per chunk
+// ===========================================================================
+// The versions above give a node 8 lanes (one per block row), so every pivot step is ~160
+// instructions of ONE wavefront (publish 4b+1 doubles, read them back, 4b+1 FMAs per lane):
+// measured 1300 cycles per pivot, 11 000 per round, and a level is 4 rounds of that.  Here
+// the 64 lanes of a wavefront share one node: lane (g, h) = (block row, column slice) holds
+// the augmented entries M[g][h + 8j] of  [L | D | U | y | I].  Per pivot step a lane
+// touches (4b+1)/8 ~ 4 entries; the pivot row index is wave-uniform (v_readlane), the pivot
+// row reaches the other rows with ds_bpermute (lane crossbar, no LDS memory, no barrier).
+// A chunk is a workgroup of 8 wavefronts = the 8 nodes that go in round 1 (later rounds
+// leave wavefronts idle at the barriers); LDS holds the chain as in version 2.
+// Same task lists, stored factors (a.crf, a.zt) and next-level rows as the other versions.
+
+// 1/x by v_rcp_f64 (about 26 bits) and two Newton steps: within an ulp or two of the IEEE
+// quotient for normal x, a third of its instructions; 1/0 = inf like the division
+__device__ __forceinline__ double tf_rcp_newton(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return r;
+}
+__device__ __forceinline__ double tf_bperm_f64(int byte_addr, double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, (int)(unsigned)(b & 0xffffffffll));
+    const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, (int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double tf_readlane_f64(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(unsigned)(b & 0xffffffffll), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+// Gauss-Jordan with partial pivoting on a b x NC augmented matrix held by one wavefront:
+// lane (g = lane & 7, h = lane >> 3) has val[j] = M[g][h + 8j]; the block to invert is columns
+// PC0 .. PC0+b-1.  Returns the row of [.. | M^-1 .. ] this lane's row ended as (rows are never
+// moved: the unused row with the largest pivot candidate serves pivot k).  Every lane of the
+// wavefront must be active.
+template <int BB, int NC, int PC0>
+__device__ __forceinline__ int tf_gj_wave(double (&val)[(NC + 7) / 8], int g, int h, bool& ok) {
+    constexpr int NJ = (NC + 7) / 8;
+    const int lane = (h << 3) | g;
+    int myk = -1;
+#pragma unroll
+    for (int kk = 0; kk < BB; ++kk) {
+        const int pc = PC0 + kk, ph = pc & 7, pj = pc >> 3;
+        unsigned key = 0;
+        if (h == ph && g < BB && myk < 0) {
+            const double cand = val[pj];
+            const float mag = (float)tf_abs(cand);
+            unsigned bits = __float_as_uint(mag);
+            if (bits == 0 && cand != 0.0) bits = 8;                // underflow is not a zero pivot
+            if (mag != mag) bits = 0x7f800000u;                    // NaN: taken, reported through ok
+            key = (bits & ~7u) | (unsigned)(7 - g);
+        }
+        // the reciprocal of every candidate is formed while the pivot is being found: the
+        // division is off the critical path (only the pivot row's one is used)
+        const double rcand = tf_rcp_newton(val[pj]);
+        const double mult = tf_bperm_f64(((ph << 3) | g) << 2, val[pj]);   // my row's entry of the pivot column
+        const unsigned best = (unsigned)__builtin_amdgcn_readlane((int)tf_group8_max(key), ph * 8);
+        const int piv = 7 - (int)(best & 7u);                      // wave-uniform
+        const int plane = (ph << 3) | piv;                         // lane that holds M[piv][pc]
+        const double rp = tf_readlane_f64(rcand, plane);
+        // the pivot row's entries of my column slice
+        double prow[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) prow[j] = tf_bperm_f64(((h << 3) | piv) << 2, val[j]);
+        if (g == piv) {
+            myk = kk;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) val[j] *= rp;
+        } else {
+            const double f2 = -mult * rp;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) val[j] = tf_fma(f2, prow[j], val[j]);
+        }
+    }
+    // a zero or non-finite pivot leaves infinities / NaNs behind: one test at the end
+    double chk = 0.0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) chk += val[j] - val[j];           // 0 for finite values, else NaN
+    if (g < BB && !(chk == 0.0)) ok = false;
+    return myk;
+}
+
+template <int BB>
+__device__ __forceinline__ void tfk_cr_factor_v3(const TfLevelArgs& a) {
+    typedef TfCr2<BB> C;
+    constexpr int NPOS = C::NPOS, B2 = BB * BB, REC = 4 * B2, NT_MIN = 256;
+    const int NT = blockDim.x, nw = NT >> 6;       // 8 wavefronts per chunk, or 4 (levels with many chunks)
+    constexpr int RS = C::RS, PS = C::PS, RW = C::RW;
+    constexpr int oL = C::oL, oD = C::oD, oU = C::oU, oY = C::oY;
+    constexpr int NC = 4 * BB + 1, NJ = (NC + 7) / 8;       // augmented columns [L | D | U | y | I]
+    constexpr int NO = 2 * BB + 1, NOJ = (NO + 7) / 8;      // outputs of one side of a phase-B task
+    static_assert(oL == 0 && oD == BB && oU == 2 * BB && oY == 3 * BB, "LDS row order = augmented order");
+    const TfLayout& L = a.L;
+    const TfCrChunk<BB> ch(L);
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane & 7, h = lane >> 3;
+    const int gq = g < BB ? g : 0;
+    const int mI = ch.mI, pe = ch.pe, len = ch.len;
+    const bool with_rhs = a.cr_rhs != 0;
+
+    __shared__ double sRow[NPOS * PS];
+    auto row = [&](int pos, int r) { return sRow + pos * PS + r * RS; };
+
+    TF_STAMP_REAL(a, 30);
+    TF_STAMP(a, 0);
+    // ---- load: records [node][L, D, U, second part of D][b][b] of a chunk are contiguous;
+    //      every request is issued before the first value is used
+    {
+        const double* src = a.Ablk + (ch.nbase + ch.start) * REC;
+        const int n3 = len * 3 * B2;
+        constexpr int NIT = (C::MAXLEN * 3 * B2 + NT_MIN - 1) / NT_MIN;
+        double v[NIT], v2[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = it * NT + tid;
+            const int nd = i / (3 * B2), rem = i - nd * 3 * B2, blk = rem / B2, rc = rem - blk * B2;
+            v[it] = i < n3 ? src[nd * REC + blk * B2 + rc] : 0.0;
+            v2[it] = (i < n3 && blk == 1) ? src[nd * REC + 3 * B2 + rc] : 0.0;     // D = both parts
+        }
+        // position 0: the separator above; only its U block couples into this chunk
+        const double* prev = a.Ablk + (ch.nbase + ch.gprev) * REC + 2 * B2;
+        double p0 = 0.0, y0 = 0.0;
+        if (tid < B2 && ch.has_prev) p0 = prev[tid];
+        const double* ys = a.rhs + (ch.nbase + ch.start) * 2 * BB;
+        if (with_rhs && tid < len * BB) y0 = ys[(tid / BB) * 2 * BB + tid % BB] + ys[(tid / BB) * 2 * BB + BB + tid % BB];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = it * NT + tid;
+            const int nd = i / (3 * B2), rem = i - nd * 3 * B2, blk = rem / B2, rc = rem - blk * B2;
+            const int r = rc / BB, c = rc - r * BB;
+            if (i < n3) row(nd + 1, r)[blk * BB + c] = v[it] + v2[it];
+        }
+        if (tid < 3 * B2) {
+            const int blk = tid / B2, rc = tid - blk * B2, r = rc / BB, c = rc - r * BB;
+            row(0, r)[blk * BB + c] = 0.0;
+        }
+        if (tid < (len + 1) * BB) row(tid / BB, tid % BB)[oY] = 0.0;
+        __syncthreads();
+        if (tid < B2) row(0, tid / BB)[oU + tid % BB] = p0;
+        if (tid < len * BB) row(tid / BB + 1, tid % BB)[oY] = y0;
+        if (!L.periodic) {                           // no neighbour beyond the ends of a system
+            if (ch.start == 0 && tid < B2) row(1, tid / BB)[oL + tid % BB] = 0.0;
+            if (ch.start + len == L.N && tid >= 64 && tid < 64 + B2) row(pe, (tid - 64) / BB)[oU + (tid - 64) % BB] = 0.0;
+        }
+    }
+    __syncthreads();
+
+    bool ok = true;
+    TF_STAMP(a, 1);
+    int stamp_i = 2;
+    for (int s = 1; s <= mI; s <<= 1) {
+        // ---- phase A: wavefront w inverts node k = s * (2w + 1)
+        const int nA = (mI / s + 1) / 2;             // <= 8
+        for (int t = w; t < nA; t += nw) {
+            const int k = s * (2 * t + 1);
+            const double* rk = row(k, gq);
+            double val[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int c = h + 8 * j;
+                val[j] = c < RW ? rk[c] : ((c < NC && c - RW == g) ? 1.0 : 0.0);
+            }
+            const int myk = tf_gj_wave<BB, NC, oD>(val, g, h, ok);
+            // my row is row myk of [E | . | F | z | D^-1]
+            if (g < BB) {
+                double* dst = row(k, myk);
+                double* rec = a.crf + (ch.nbase + ch.node(k)) * 5 * B2 + myk * BB;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int c = h + 8 * j;
+                    if (c < RW) dst[c] = val[j];                     // (the D slot is dead from here on)
+                    if (c < BB) rec[1 * B2 + c] = val[j];
+                    else if (c >= oU && c < oY) rec[2 * B2 + c - oU] = val[j];
+                    else if (c == oY) { if (with_rhs) a.zt[(ch.nbase + ch.node(k)) * BB + myk] = val[j]; }
+                    else if (c > oY && c < NC) rec[c - RW] = val[j];
+                }
+            }
+        }
+        __syncthreads();
+        TF_STAMP(a, stamp_i); ++stamp_i;
+        // ---- phase B: wavefront w updates the neighbours of task t.  Interior a = 2s(t+1):
+        //      its L side lost kL = a-s, its U side loses kR = a+s (if there).  Last task: the
+        //      L side of the own separator (pe) and the U side of position 0.
+        const int nB = mI / (2 * s);                 // <= 7
+        for (int t = w; t <= nB; t += nw) {
+            const bool ends = t == nB;
+            const int aa = 2 * s * (t + 1), nq = mI / s;
+            const int aL = ends ? pe : aa, aU = ends ? 0 : aa;
+            const bool vL = ends ? (nq & 1) != 0 : true;
+            const bool vR = ends ? true : aa + s <= mI;
+            const int kL = ends ? nq * s : aa - s, kR = ends ? s : aa + s;
+            // Row aL loses kL through its L block, row aU loses kR through its U block.  Lane
+            // (g, h) owns column h of row g of every output block:
+            //   j = 0: L' = -L E_kL   (h == b: y_aL -= L z_kL)     j = 2: D_aL -= L F_kL
+            //   j = 1: U' = -U F_kR   (h == b: y_aU -= U z_kR)     j = 3: D_aU -= U E_kR
+            // so the two updates of one D block (interior tasks: aL == aU) meet in one lane and
+            // are applied in the order of the other versions.  (b == 8: the y updates are j = 4.)
+            double* raL = row(aL, gq);
+            double* raU = row(aU, gq);
+            const int kLs = vL ? kL : 1, kRs = vR ? kR : 1;
+            double Lr[BB], Ur[BB];
+#pragma unroll
+            for (int m = 0; m < BB; ++m) { Lr[m] = raL[oL + m]; Ur[m] = raU[oU + m]; }
+            constexpr bool YSEP = BB >= 8;
+            const int hc = h < BB ? h : 0;
+            const bool isy = !YSEP && h == BB;
+            const double oldDL = raL[oD + hc], oldDU = raU[oD + hc];
+            const double oldYL = raL[oY], oldYU = raU[oY];
+            // stored for the solves: the blocks used in this elimination (Lb of kL, Ua of kR)
+            if (g < BB && h < BB) {
+                if (vL) a.crf[(ch.nbase + ch.node(kL)) * 5 * B2 + 4 * B2 + g * BB + h] = raL[oL + h];
+                if (vR) a.crf[(ch.nbase + ch.node(kR)) * 5 * B2 + 3 * B2 + g * BB + h] = raU[oU + h];
+            }
+            const int s0 = isy ? oY : oL + hc, s1 = isy ? oY : oU + hc;      // source columns of j = 0, 1
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, y0 = 0.0, y1 = 0.0;
+#pragma unroll
+            for (int m = 0; m < BB; ++m) {
+                const double* eL = row(kLs, m);
+                const double* eR = row(kRs, m);
+                a0 = tf_fma(-Lr[m], eL[s0], a0);
+                a1 = tf_fma(-Ur[m], eR[s1], a1);
+                a2 = tf_fma(-Lr[m], eL[oU + hc], a2);
+                a3 = tf_fma(-Ur[m], eR[oL + hc], a3);
+                if (YSEP) { y0 = tf_fma(-Lr[m], eL[oY], y0); y1 = tf_fma(-Ur[m], eR[oY], y1); }
+            }
+            if (g < BB) {
+                if (h < BB) {
+                    if (vL) raL[oL + h] = a0;
+                    if (vR) raU[oU + h] = a1;
+                    if (aL == aU) {
+                        double d = oldDL;
+                        if (vL) d += a2;
+                        if (vR) d += a3;
+                        raL[oD + h] = d;
+                    } else {
+                        if (vL) raL[oD + h] = oldDL + a2;
+                        if (vR) raU[oD + h] = oldDU + a3;
+                    }
+                }
+                const bool ylane = YSEP ? h == 0 : h == BB;
+                if (ylane) {
+                    const double yl = YSEP ? y0 : a0, yu = YSEP ? y1 : a1;
+                    if (aL == aU) {
+                        double d = oldYL;
+                        if (vL) d += yl;
+                        if (vR) d += yu;
+                        raL[oY] = d;
+                    } else {
+                        if (vL) raL[oY] = oldYL + yl;
+                        if (vR) raU[oY] = oldYU + yu;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        TF_STAMP(a, stamp_i); ++stamp_i;
+    }
+
+    // ---- this chunk's share of the next level's rows: node p gets (L, D, y) of position pe,
+    //      node p-1 gets (U, second part of D, second part of y) of position 0
+    if (tid < 2 * BB * NO) {
+        const int side = tid / (BB * NO), rem = tid - side * BB * NO, r = rem / NO, o = rem - r * NO;
+        const int nn = side == 0 ? ch.p : ch.pprev;
+        double* rec = a.Anext + ((int64_t)ch.e * a.Lnext.N + nn) * REC;
+        double* rr = a.rhsnext + ((int64_t)ch.e * a.Lnext.N + nn) * 2 * BB;
+        const double* rs = row(side == 0 ? pe : 0, r);
+        if (o < BB) rec[(side == 0 ? 0 : 2) * B2 + r * BB + o] = rs[(side == 0 ? oL : oU) + o];
+        else if (o < 2 * BB) rec[(side == 0 ? 1 : 3) * B2 + r * BB + o - BB] = rs[oD + o - BB];
+        else if (with_rhs) rr[(side == 0 ? 0 : BB) + r] = rs[oY];
+    }
+    TF_STAMP(a, 20);
+    if (a.fold_top) {
+        // one chunk per system: what is left of rows 0 and pe couples the separator to
+        // itself only (TfTopArgs): invert their sum here, and solve for the first rhs
+        __syncthreads();
+        constexpr int NCT = 2 * BB + 1, NJT = (NCT + 7) / 8;     // [S | y | I]
+        if (w == 0) {
+            const double* r0 = row(0, gq);
+            const double* rp = row(pe, gq);
+            double val[NJT];
+#pragma unroll
+            for (int j = 0; j < NJT; ++j) {
+                const int c = h + 8 * j;
+                val[j] = c < BB ? rp[oL + c] + rp[oD + c] + r0[oU + c] + r0[oD + c]
+                       : (c == BB ? rp[oY] + r0[oY] : ((c < NCT && c - BB - 1 == g) ? 1.0 : 0.0));
+            }
+            const int myk = tf_gj_wave<BB, NCT, 0>(val, g, h, ok);
+            if (g < BB) {
+                const int nsys = L.Ptot;             // P == 1
+#pragma unroll
+                for (int j = 0; j < NJT; ++j) {
+                    const int c = h + 8 * j;
+                    if (c > BB && c < NCT) a.topAinv[(int64_t)(myk * BB + c - BB - 1) * nsys + ch.e] = val[j];
+                    if (c == BB && with_rhs) {
+                        // ... and the solution of the top block: the y slots take the solution
+                        const double x = val[j];
+                        a.topx[(int64_t)ch.e * BB + myk] = x;
+                        a.x[(ch.nbase + ch.node(pe)) * BB + myk] = x;
+                        row(pe, myk)[oY] = x;
+                        row(0, myk)[oY] = ch.has_prev ? x : 0.0;
+                    }
+                }
+            }
+        }
+        if (with_rhs) {
+            // back-substitution of this level (tfk_cr_bwd_coop): E_k, F_k and z_k are in LDS
+            __syncthreads();
+            int s = 1;
+            while (2 * s <= mI) s <<= 1;
+            for (; s >= 1; s >>= 1) {
+                const int nA = (mI / s + 1) / 2;
+                for (int t = w; t < nA; t += nw) {
+                    if (!(h == 0 && g < BB)) continue;
+                    const int k = s * (2 * t + 1);
+                    const int kl = k - s, kr = k + s <= mI ? k + s : pe;
+                    double* rk = row(k, g);
+                    double xk = rk[oY];
+#pragma unroll
+                    for (int m = 0; m < BB; ++m) {
+                        xk = tf_fma(-rk[oL + m], row(kl, m)[oY], xk);
+                        xk = tf_fma(-rk[oU + m], row(kr, m)[oY], xk);
+                    }
+                    rk[oY] = xk;
+                    a.x[(ch.nbase + ch.node(k)) * BB + g] = xk;
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (!ok && lane == 0) *a.status = 1;
+    TF_STAMP(a, 21);
+    TF_STAMP_REAL(a, 31);
+}

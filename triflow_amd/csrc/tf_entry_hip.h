@@ -5,6 +5,10 @@
 #pragma once
 
 #include "tf_coop_hip.h"
+#ifndef TF_CR_V2
+#define TF_CR_V2 3        // 0: first version (tf_coop_hip.h), 2 / 3: tf_cr2_hip.h
+#endif
+#include "tf_cr2_hip.h"
 
 #define TF_GID ((int)(blockIdx.x * blockDim.x + threadIdx.x))
 
@@ -125,7 +129,29 @@ __global__ void __launch_bounds__(64) tfk_l1_solve(TfLevelArgs a) {
     if (blockIdx.y == 0) tfk_chunk_body<TfRowsL1, +1, false, false, true>(a, TF_GID);
     else tfk_chunk_body<TfRowsL1, -1, false, false, false>(a, TF_GID);
 }
-__global__ void __launch_bounds__(64) tfk_l1_asm_mat(TfLevelArgs a) { tfk_asm_body<TfRowsL1, true>(a, TF_GID); }
+// The next level's rows.  When that level keeps records per node (cyclic reduction), the 64
+// rows of a workgroup are collected in LDS and leave as whole records: coalesced stores of
+// 3*b*b contiguous doubles per separator instead of 8 bytes per lane and instruction.
+__global__ void __launch_bounds__(64) tfk_l1_asm_mat(TfLevelArgs a) {
+    constexpr int NREC = 3 * TF_B2 * TF_B2, SW = NREC | 1;           // odd stride: no bank conflicts
+    if constexpr (SW * 64 * 8 <= 64 * 1024) {
+        if (a.next_aos) {
+            __shared__ double stage[64 * SW];
+            tfk_asm_body<TfRowsL1, true>(a, TF_GID, stage + threadIdx.x * SW);
+            __syncthreads();
+            // node (e, p) of the next level is record e * Lnext.N + p = pg (Lnext.N == L.P)
+            const int pg0 = blockIdx.x * 64;
+            const int nrec = a.L.Ptot - pg0 < 64 ? a.L.Ptot - pg0 : 64;
+            double* dst = a.Anext + (int64_t)pg0 * 4 * TF_B2 * TF_B2;
+            for (int idx = threadIdx.x; idx < nrec * NREC; idx += 64) {
+                const int t = idx / NREC, off = idx - t * NREC;
+                dst[(int64_t)t * 4 * TF_B2 * TF_B2 + off] = stage[t * SW + off];
+            }
+            return;
+        }
+    }
+    tfk_asm_body<TfRowsL1, true>(a, TF_GID);
+}
 __global__ void __launch_bounds__(64) tfk_l1_asm_rhs(TfLevelArgs a) { tfk_asm_body<TfRowsL1, false>(a, TF_GID); }
 __global__ void __launch_bounds__(64) tfk_l1_backsub(TfLevelArgs a) { tfk_backsub_body<TfRowsL1>(a, TF_GID); }
 
@@ -168,9 +194,15 @@ __global__ void __launch_bounds__(64) tfk_top_solve(TfTopArgs a) { tfk_top_body<
 // ---- cyclic-reduction levels (tf_coop_hip.h): 3 <= b <= 8 one wavefront per 16-node chunk
 //      (8 lanes per node); b <= 2 one thread per node, 256-node chunks
 #define TF_CR_BLOCK (TF_B2 <= 2 ? 256 : 64)
-__global__ void __launch_bounds__(TF_CR_BLOCK) tfk_cr_factor(TfLevelArgs a) {
+// the factorisation of 3 <= b <= 8: 8 wavefronts per chunk (version 3), else one
+#define TF_CR_FACTOR_BLOCK (TF_B2 <= 2 ? 256 : (TF_CR_V2 == 3 ? 512 : 64))
+__global__ void __launch_bounds__(TF_CR_FACTOR_BLOCK) tfk_cr_factor(TfLevelArgs a) {
     if constexpr (TF_B2 <= 2) tfk_crs_factor<TF_B2>(a);
-    else if constexpr (TF_B2 <= 8) tfk_cr_factor_coop<TF_B2>(a);
+    else if constexpr (TF_B2 <= 8) {
+        if constexpr (TF_CR_V2 == 3) tfk_cr_factor_v3<TF_B2>(a);
+        else if constexpr (TF_CR_V2 == 2) tfk_cr_factor_v2<TF_B2>(a);
+        else tfk_cr_factor_coop<TF_B2>(a);
+    }
 }
 __global__ void __launch_bounds__(TF_CR_BLOCK) tfk_cr_fwd(TfLevelArgs a) {
     if constexpr (TF_B2 <= 2) tfk_crs_fwd<TF_B2>(a);

@@ -38,6 +38,19 @@
 
 #include "tf_math.h"
 
+// In-kernel stamps of a diagnostic build (-DTF_STAMPS, tools/gpu_stamps.py): lane 0 of the
+// middle workgroup records the shader clock at phase boundaries.  No stamp executes in the
+// product build, and nothing computed ever depends on one.
+#if defined(TF_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#define TF_STAMP(a, i) do { if ((a).stamps && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) \
+        (a).stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TF_STAMP_REAL(a, i) do { if ((a).stamps && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) \
+        (a).stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TF_STAMP(a, i) do {} while (0)
+#define TF_STAMP_REAL(a, i) do {} while (0)
+#endif
+
 // ------------------------------------------------------------------- layout
 TF_DEVICE int tf_len(const TfLayout& L, int p) { return L.mbase + (p < L.rem ? 1 : 0); }
 TF_DEVICE int tf_start(const TfLayout& L, int p) { return p * L.mbase + (p < L.rem ? p : L.rem); }
@@ -669,6 +682,9 @@ struct TfRowsBT {
 #ifndef TF_PREFETCH_DEEP
 #define TF_PREFETCH_DEEP(spike) (!(spike))
 #endif
+#ifndef TF_BACKSUB_DEPTH
+#define TF_BACKSUB_DEPTH 3
+#endif
 
 // ---- interior elimination of one chunk in one direction --------------------
 // DIR = +1 walks down (local j <-> node j), DIR = -1 walks up (local j <-> node
@@ -1059,8 +1075,11 @@ TF_DEVICE void tfk_bt_col_body(const TfLevelArgs& a, int pg, int dir, int col) {
 
 // ---- interface (separator) equations -> next level --------------------------
 // MATRIX: build the [3][b][b] block row (factor phase); always builds the rhs.
+// `stage` (optional): the block row goes there as [3][b][b] instead of to a.Anext -- the HIP
+// entry point collects the rows of a workgroup in LDS and writes whole records (a thread's own
+// 8-byte stores into records of 4*b*b doubles are the slowest thing this kernel can do).
 template <class Rows, bool MATRIX>
-TF_DEVICE void tfk_asm_body(const TfLevelArgs& a, int pg) {
+TF_DEVICE void tfk_asm_body(const TfLevelArgs& a, int pg, double* stage = nullptr) {
     constexpr int B = Rows::B, MP = Rows::MP, W = 2 * MP + 1, BB = MP * B;
     typedef TfTips<B, MP> Tip;
     const TfLayout& L = a.L;
@@ -1145,9 +1164,15 @@ TF_DEVICE void tfk_asm_body(const TfLevelArgs& a, int pg) {
 #pragma unroll
                     for (int c = 0; c < B; ++c) {
                         const int rr = t * B + r, cc = t2 * B + c;
-                        a.Anext[tf_next_A(a, e, p, s2, 0, rr, cc, BB)] = sub[t2][r][c];
-                        a.Anext[tf_next_A(a, e, p, s2, 1, rr, cc, BB)] = dia[t2][r][c];
-                        a.Anext[tf_next_A(a, e, p, s2, 2, rr, cc, BB)] = sup[t2][r][c];
+                        if (stage) {
+                            stage[(0 * BB + rr) * BB + cc] = sub[t2][r][c];
+                            stage[(1 * BB + rr) * BB + cc] = dia[t2][r][c];
+                            stage[(2 * BB + rr) * BB + cc] = sup[t2][r][c];
+                        } else {
+                            a.Anext[tf_next_A(a, e, p, s2, 0, rr, cc, BB)] = sub[t2][r][c];
+                            a.Anext[tf_next_A(a, e, p, s2, 1, rr, cc, BB)] = dia[t2][r][c];
+                            a.Anext[tf_next_A(a, e, p, s2, 2, rr, cc, BB)] = sup[t2][r][c];
+                        }
                     }
         }
     }
@@ -1207,25 +1232,36 @@ TF_DEVICE void tfk_backsub_body(const TfLevelArgs& a, int pg) {
                     if (c < MP) n.E[c < MP ? c : 0][r][k] = a.Et[(int64_t)((c * B + r) * B + k) * L.plane + s];
                 }
     };
-    Node cur = {}, nxt = {};
-    load(mI - 1, cur);
-    for (int j = mI - 1; j >= 0; --j) {
-        if (j > 0) load(j - 1, nxt);
-        const int64_t s = tf_idx(L, pg, j);
-        double x[B];
+    // TF_BACKSUB_DEPTH nodes of factors in flight per thread: the walk is a chain of loads
+    // (few wavefronts: one lane per chunk), so its speed is the number of requests that are
+    // outstanding, not the arithmetic.  The ring is unrolled: every index is static.
+    constexpr int D = TF_BACKSUB_DEPTH;
+    Node ring[D];
 #pragma unroll
-        for (int r = 0; r < B; ++r) x[r] = cur.y[r];
+    for (int d = 0; d < D; ++d)
+        if (mI - 1 - d >= 0) load(mI - 1 - d, ring[d]);
+    for (int j0 = mI - 1; j0 >= 0; j0 -= D) {
 #pragma unroll
-        for (int c = 0; c < UW; ++c) tf_mv_sub<B>(x, cur.U[c], xn[c]);
+        for (int d = 0; d < D; ++d) {
+            const int j = j0 - d;
+            if (j < 0) break;
+            const Node& cur = ring[d];
+            const int64_t s = tf_idx(L, pg, j);
+            double x[B];
 #pragma unroll
-        for (int c = 0; c < MP; ++c) tf_mv_sub<B>(x, cur.E[c], sa[c]);
+            for (int r = 0; r < B; ++r) x[r] = cur.y[r];
 #pragma unroll
-        for (int c = UW - 1; c > 0; --c)
+            for (int c = 0; c < UW; ++c) tf_mv_sub<B>(x, cur.U[c], xn[c]);
 #pragma unroll
-            for (int r = 0; r < B; ++r) xn[c][r] = xn[c - 1][r];
+            for (int c = 0; c < MP; ++c) tf_mv_sub<B>(x, cur.E[c], sa[c]);
 #pragma unroll
-        for (int r = 0; r < B; ++r) { xn[0][r] = x[r]; a.x[(int64_t)r * L.plane + s] = x[r]; }
-        cur = nxt;
+            for (int c = UW - 1; c > 0; --c)
+#pragma unroll
+                for (int r = 0; r < B; ++r) xn[c][r] = xn[c - 1][r];
+#pragma unroll
+            for (int r = 0; r < B; ++r) { xn[0][r] = x[r]; a.x[(int64_t)r * L.plane + s] = x[r]; }
+            if (j - D >= 0) load(j - D, ring[d]);
+        }
     }
 }
 

@@ -97,6 +97,14 @@ struct tf_solver {
     // storage of what a level hands to the next one: records per node (below a cyclic-
     // reduction level) or partition-interleaved planes
     unsigned cr_block() const { return top.B <= 2 ? 256u : 64u; }     // TF_CR_BLOCK of tf_entry_hip.h
+    // wavefront for each of the 8 nodes of round 1; a level with more chunks than the GPU
+    // holds at once (4 such workgroups per CU) takes 4 wavefronts per chunk, twice the chunks in flight
+    unsigned cr_factor_block(int64_t chunks) const {
+        if (top.B <= 2) return 256u;
+        const char* v = getenv("TRIFLOW_CR_FACTOR_BLOCK");
+        if (v) return (unsigned)atoi(v);
+        return chunks > 1024 ? 256u : 512u;
+    }
     // the last level is a cyclic-reduction level: it handles the top block itself
     bool fold_top() const { return levels.size() > 1 && levels.back()->cr; }
     bool level_cr(size_t l) const { return l < levels.size() && levels[l]->cr; }
@@ -129,6 +137,7 @@ struct tf_solver {
     int *dir_var = nullptr, *dir_node = nullptr;
     DevBuf dir_val, dir_val_post;   // values applied before the step (hook at t) / after (t+dt)
 
+    DevBuf stamp_buf;              // diagnostic builds: 64 stamps per solver level (tf_debug_stamps)
     char* poke_buf = nullptr;      // scratch of tf_poke
     size_t poke_bytes = 0;
 
@@ -329,6 +338,7 @@ struct tf_solver {
         a.next_aos = next_aos(l) ? 1 : 0; a.crf = lv.crf.p; a.zt = lv.zt.p;
         a.fold_top = fold_top() && l + 1 == levels.size() ? 1 : 0;
         a.topAinv = topAinv.p; a.topx = top.x.p;
+        a.stamps = stamp_buf.n ? (unsigned long long*)stamp_buf.p + 64 * l : nullptr;
         return a;
     }
     TfTopArgs top_args() {
@@ -354,7 +364,7 @@ struct tf_solver {
             else if (levels[l]->cr) {
                 // one wavefront per chunk; leaves the next level's rows (and rhs) behind
                 a.cr_rhs = fused ? 1 : 0;
-                launch(TFK_CR_FACTOR, (unsigned)a.L.Ptot, 1, cr_block(), &a, sizeof(a));
+                launch(TFK_CR_FACTOR, (unsigned)a.L.Ptot, 1, cr_factor_block(a.L.Ptot), &a, sizeof(a));
                 continue;
             } else {
                 const int G = tfb::coop_group(levels[l]->B);
@@ -905,27 +915,24 @@ int tf_matvec(tf_solver* s, const double* v_flat, double* y_flat) {
 }
 
 // --------------------------------------------------------------- seam #2
+}  // extern "C"
+namespace {
 // Theta scheme, reference schemes.py:548-559:
 //   fields = copy; hook(t); F, J; B = dt*(F - theta*J@U) + U; A = I - theta*dt*J;
 //   U+ = solve(A, B); hook(t+dt)
-int tf_step_theta(tf_solver* s, int32_t src, int32_t dst, double dt, double theta) {
-    TF_API_BEGIN
-    require(s, "null solver");
+void step_theta(tf_solver* s, int32_t src, int32_t dst, double dt, double theta) {
     require(src != dst, "tf_step_theta: src and dst slots must differ");
     double* U = s->st(dst);
     const double* Uin = s->stage_input(src, U);                    // copy + hook only when there is a hook
     s->sweep_theta(Uin, dt, theta, s->Wrhs.p);                     // F, J, dt*(F - (theta*J)@U) + U
     s->factor(theta * dt, s->Wrhs.p, U);
     s->apply_dirichlet(U, true);
-    TF_API_END
 }
 
-// Rosenbrock-Wanner fixed step, reference schemes.py:142-174.
-int tf_step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns,
-                const double* alpha, const double* gamma, const double* b,
-                const double* b_pred, int32_t hook_after, double* err_out) {
-    TF_API_BEGIN
-    require(s && alpha && gamma && b, "null argument");
+// Rosenbrock-Wanner fixed step, reference schemes.py:142-174.  With b_pred the maximum of
+// |U - U_pred| is left in red[0] (the caller reads it).
+void step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns, const double* alpha,
+              const double* gamma, const double* b, const double* b_pred, bool hook_after, bool want_err) {
     require(ns >= 1 && ns <= 6, "tf_step_row: 1 <= s <= 6");
     require(src != dst, "tf_step_row: src and dst slots must differ");
     double* U = s->st(dst);
@@ -947,12 +954,51 @@ int tf_step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns,
     }
     for (int j = 0; j < ns; ++j) { ks[j] = s->K[j].p; cs[j] = b[j]; }
     s->vec(TF_VEC_SUM, U, Uin, ns, ks, cs);                        // U + sum_i b_i k_i
-    if (b_pred && err_out) {
+    if (b_pred && want_err) {
         tfb::memset0(s->red.p, sizeof(double), s->stream);
         for (int j = 0; j < ns; ++j) cs[j] = b_pred[j];
         s->vec(TF_VEC_MAXABS, nullptr, U, ns, ks, cs);             // ||U - (U + sum b_pred k)||_inf
     }
     if (hook_after) s->apply_dirichlet(U, true);
+}
+
+// per system and variable ||state[a] - state[b]||_ord (ord 2 / 0 = max), out[nsys][nvar]
+void diff_norm(tf_solver* s, int32_t slot_a, int32_t slot_b, int32_t ord, double* out) {
+    require(ord == 0 || ord == 2, "tf_diff_norm: ord must be 2 or 0 (max norm)");
+    const int nb = 64, nvs = s->spec.nvar * s->nsys;
+    if (s->normbuf.n < (size_t)nb * nvs) s->normbuf.alloc((size_t)nb * nvs, s->bytes);
+    TfNormArgs a;
+    a.L = s->L1; a.a = s->st(slot_a); a.b = s->st(slot_b); a.partial = s->normbuf.p;
+    a.nblocks = nb; a.ord = ord;
+    s->launch(TFK_DIFFNORM, nb, nvs, 256, &a, sizeof(a));
+    std::vector<double> part((size_t)nb * nvs);
+    tfb::d2h(part.data(), s->normbuf.p, part.size() * sizeof(double), s->stream);
+    for (int vs = 0; vs < nvs; ++vs) {                 // fixed order: deterministic
+        double acc = 0.0;
+        for (int b = 0; b < nb; ++b) {
+            const double v = part[(size_t)vs * nb + b];
+            acc = ord == 2 ? acc + v : (v > acc ? v : acc);
+        }
+        const int v = vs / s->nsys, e = vs % s->nsys;
+        out[(size_t)e * s->spec.nvar + v] = ord == 2 ? std::sqrt(acc) : acc;
+    }
+}
+}  // namespace
+extern "C" {
+
+int tf_step_theta(tf_solver* s, int32_t src, int32_t dst, double dt, double theta) {
+    TF_API_BEGIN
+    require(s, "null solver");
+    step_theta(s, src, dst, dt, theta);
+    TF_API_END
+}
+
+int tf_step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns,
+                const double* alpha, const double* gamma, const double* b,
+                const double* b_pred, int32_t hook_after, double* err_out) {
+    TF_API_BEGIN
+    require(s && alpha && gamma && b, "null argument");
+    step_row(s, src, dst, dt, ns, alpha, gamma, b, b_pred, hook_after != 0, err_out != nullptr);
     if (err_out) {
         *err_out = 0.0;
         if (b_pred) {
@@ -962,6 +1008,50 @@ int tf_step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns,
         }
         s->check_status();
     }
+    TF_API_END
+}
+
+// One trial of the step-doubling controller that the reference wraps around every scheme
+// (schemes.py:33-66, simulation.py:190-197): a coarse step m*dt against `nfine` fine steps
+// dt from the same state, and the difference of the two results -- all queued back to back;
+// the host waits once, for the norms.  src -> coarse (one step m*dt); src -> tmp -> dst ->
+// tmp ... -> dst (nfine steps, nfine even); err_out[nsys] = max_var ||coarse - dst||_ord / (m^2 - 1).
+int tf_step_doubling(tf_solver* s, int32_t src, int32_t dst, int32_t tmp, int32_t coarse, double dt,
+                     int32_t m, int32_t nfine, const tf_scheme* sch, int32_t ord, double* err_out) {
+    TF_API_BEGIN
+    require(s && sch && err_out, "null argument");
+    require(nfine >= 2 && nfine % 2 == 0, "tf_step_doubling: the fine steps ping-pong between two slots (nfine even)");
+    require(m >= 2, "tf_step_doubling: m >= 2");
+    const int32_t slots[4] = {src, dst, tmp, coarse};
+    for (int i = 0; i < 4; ++i)
+        for (int j = i + 1; j < 4; ++j) require(slots[i] != slots[j], "tf_step_doubling: the four slots must differ");
+    require(sch->kind == TF_SCHEME_THETA || sch->kind == TF_SCHEME_ROW, "tf_step_doubling: scheme kind");
+    auto one = [&](int32_t from, int32_t to, double h) {
+        if (sch->kind == TF_SCHEME_THETA) step_theta(s, from, to, h, sch->theta);
+        else {
+            require(sch->alpha && sch->gamma && sch->b, "tf_step_doubling: tableau");
+            step_row(s, from, to, h, sch->stages, sch->alpha, sch->gamma, sch->b, nullptr,
+                     sch->hook_after != 0, false);
+        }
+    };
+    one(src, coarse, m * dt);
+    int32_t from = src;
+    for (int i = 0; i < nfine; ++i) {
+        const int32_t to = (i % 2 == 0) ? tmp : dst;
+        one(from, to, dt);
+        from = to;
+    }
+    std::vector<double> norms((size_t)s->nsys * s->spec.nvar);
+    diff_norm(s, coarse, dst, ord, norms.data());                  // the one synchronisation
+    for (int e = 0; e < s->nsys; ++e) {
+        double worst = 0.0;
+        for (int v = 0; v < s->spec.nvar; ++v) {
+            const double n = norms[(size_t)e * s->spec.nvar + v];
+            worst = (n > worst || n != n) ? n : worst;
+        }
+        err_out[e] = worst / ((double)m * m - 1.0);
+    }
+    s->check_status();
     TF_API_END
 }
 
@@ -1026,24 +1116,7 @@ int tf_bdf2_release(tf_solver* s, int64_t owner) {
 int tf_diff_norm(tf_solver* s, int32_t slot_a, int32_t slot_b, int32_t ord, double* out) {
     TF_API_BEGIN
     require(s && out, "null argument");
-    require(ord == 0 || ord == 2, "tf_diff_norm: ord must be 2 or 0 (max norm)");
-    const int nb = 64, nvs = s->spec.nvar * s->nsys;
-    if (s->normbuf.n < (size_t)nb * nvs) s->normbuf.alloc((size_t)nb * nvs, s->bytes);
-    TfNormArgs a;
-    a.L = s->L1; a.a = s->st(slot_a); a.b = s->st(slot_b); a.partial = s->normbuf.p;
-    a.nblocks = nb; a.ord = ord;
-    s->launch(TFK_DIFFNORM, nb, nvs, 256, &a, sizeof(a));
-    std::vector<double> part((size_t)nb * nvs);
-    tfb::d2h(part.data(), s->normbuf.p, part.size() * sizeof(double), s->stream);
-    for (int vs = 0; vs < nvs; ++vs) {                 // fixed order: deterministic
-        double acc = 0.0;
-        for (int b = 0; b < nb; ++b) {
-            const double v = part[(size_t)vs * nb + b];
-            acc = ord == 2 ? acc + v : (v > acc ? v : acc);
-        }
-        const int v = vs / s->nsys, e = vs % s->nsys;
-        out[(size_t)e * s->spec.nvar + v] = ord == 2 ? std::sqrt(acc) : acc;
-    }
+    diff_norm(s, slot_a, slot_b, ord, out);
     TF_API_END
 }
 
@@ -1052,6 +1125,18 @@ int tf_backward_error(tf_solver* s, double* omega, int32_t* refined) {
     require(s, "null solver");
     if (omega) *omega = s->last_omega;
     if (refined) *refined = s->fact_needs_refine ? 1 : 0;
+    TF_API_END
+}
+
+// Diagnostic builds of the kernels (-DTF_STAMPS) record clock stamps per solver level:
+// out[level][64] 64-bit counters; the first call switches the recording on.
+int tf_debug_stamps(tf_solver* s, uint64_t* out, int32_t max_levels) {
+    TF_API_BEGIN
+    require(s && out, "null argument");
+    const size_t need = 64 * std::max<size_t>(s->levels.size(), 1);
+    if (s->stamp_buf.n < need) { s->stamp_buf.alloc(need, s->bytes); return 0; }
+    const size_t n = 64 * std::min<size_t>(s->levels.size(), (size_t)std::max(max_levels, 0));
+    tfb::d2h(out, s->stamp_buf.p, n * sizeof(uint64_t), s->stream);
     TF_API_END
 }
 

@@ -86,21 +86,54 @@ def _difference_norms(a, b, ord):
             for key in b.dependent_variables]
 
 
+def _fused_trial(scheme, t, fields, dt_, m, pars, hook, ord):
+    """One trial of the step-doubling controller as ONE call into the device library
+    (``tf_step_doubling``: the coarse step, the ten fine steps and the norm of their
+    difference are queued back to back, the host waits once) -- possible when the scheme
+    is a fixed-step device scheme and the hook needs no host work between sub-steps
+    (none, or a :class:`DirichletHook` with constant values).  Returns
+    ``(fields after the fine steps, err)`` or ``None`` when the trial has to be driven
+    step by step from Python (same results, eleven host round trips)."""
+    desc = getattr(scheme, "_device_desc", lambda: None)()
+    if desc is None or ord not in (2, np.inf) or not _is_device_hook(hook):
+        return None
+    if isinstance(hook, DirichletHook) and (hook.time_dependent or hook.parameters is not None):
+        return None
+    stepper = stepper_for(scheme._model, fields, pars)
+    if stepper.nstate < 5 or stepper.solver.nsys != 1:
+        return None
+    stepper.bind(fields, pars)
+    stepper.set_hook(hook, t, t)
+    src = stepper.acquire(fields)
+    coarse = stepper.free_slot(exclude=(src,))
+    tmp = stepper.free_slot(exclude=(src, coarse))
+    dst = stepper.free_slot(exclude=(src, coarse, tmp))
+    err = stepper.solver.step_doubling(src, dst, tmp, coarse, dt_, m, desc, ord)[0]
+    return stepper.wrap(fields, dst), err
+
+
 def time_stepping(scheme, tol=1e-1, ord=2, m=10, reject_factor=2):
     """Step-doubling control around any scheme (``schemes.py:33-66``): a coarse
     step ``m*dt`` against ten fine steps (the reference's literal 10), error
     ``max_var ||coarse - fine||_ord / (m**2 - 1)``, new ``dt`` from
     ``sqrt(dt**2 * tol / err)``, retried while it shrinks by more than
-    ``reject_factor``.  The internal ``dt`` persists across calls."""
+    ``reject_factor``.  The internal ``dt`` persists across calls.  A trial runs as one
+    device call when it can (:func:`_fused_trial`)."""
     state = {"dt": None}
 
     def one_step(t, fields, dt, pars, hook):
         dt_ = dt
         while True:
-            _, coarse = scheme(t, fields, m * dt_, pars, hook)
-            for _ in range(10):
-                t, fields = scheme(t, fields, dt_, pars, hook)
-            err = max(_difference_norms(coarse, fields, ord)) / (m ** 2 - 1)
+            fused = _fused_trial(scheme, t, fields, dt_, m, pars, hook, ord)
+            if fused is not None:
+                fields, err = fused
+                for _ in range(10):
+                    t = t + dt_                  # the reference's ten additions, same bits
+            else:
+                _, coarse = scheme(t, fields, m * dt_, pars, hook)
+                for _ in range(10):
+                    t, fields = scheme(t, fields, dt_, pars, hook)
+                err = max(_difference_norms(coarse, fields, ord)) / (m ** 2 - 1)
             dt_ = np.sqrt(dt ** 2 * tol / err)
             if dt_ < dt / reject_factor:
                 continue        # as in the reference, the retry starts from the advanced state
@@ -127,6 +160,10 @@ class Theta:
 
     def __init__(self, model, theta=1, solver=None):
         self._model, self._theta, self._solver = model, theta, solver
+
+    def _device_desc(self):
+        """What ``tf_step_doubling`` needs to run this scheme's steps itself."""
+        return None if self._solver is not None else dict(kind="theta", theta=self._theta)
 
     def __call__(self, t, fields, dt, pars, hook=null_hook):
         if self._solver is not None:
@@ -173,6 +210,12 @@ class ROW_general:
         self._internal_iter = None
         self._interp_cache = None
         self._err = None
+
+    def _device_desc(self):
+        """What ``tf_step_doubling`` needs to run this scheme's (fixed) steps itself."""
+        if self._time_control:
+            return None          # the embedded-error control decides step by step on the host
+        return dict(kind="row", alpha=self._alpha, gamma=self._gamma, b=self._b, hook_after=True)
 
     def __call__(self, t, fields, dt, pars, hook=null_hook):
         if self._time_control:
