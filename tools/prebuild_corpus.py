@@ -10,5 +10,5 @@ for name in sorted(corpus.MODELS):
     t = time.time()
     m = Model(*corpus.model_args(name), compiler=lambda m: (None, None))
     for mask in (0,):
-        compilers.build_code_object(m, mask)
+        compilers.build_code_object(m, mask, seg=4)      # test sizes are small: TF_SEG = 4
     print("%-16s %.1fs" % (name, time.time() - t), flush=True)

@@ -257,15 +257,22 @@ def lower_model(model, parvec_mask=0, seg=8, sweep_block=64):
     emit_j, j_c = emit_all(j_nodes)
     uses_x = any("xc" in _tokens(s) for s in f_c + j_c)
 
-    def body(outname, exprs, emitter):
-        lines = ["    " + d for d in decls]
+    # Jacobian entries that are the same at every node of a system (constant coefficients:
+    # only dx, scalar parameters and constants): the solver kernels evaluate them once per
+    # thread instead of reading them back from the value table at every node
+    j_uniform = [1 if emit_j.is_uniform(n) else 0 for n in j_nodes]
+
+    def body(outname, exprs, emitter, only=None):
+        lines = ["    " + d for d in decls if only is None or d.split("=")[1].strip().startswith("par[")]
         lines += ["    const double* tf_hc = par + %d;" % len(pars)]
         lines += ["    (void)dx; (void)xc; (void)par; (void)tf_hc;"]
         # node-independent divisors and their reciprocals: loop invariant, hoisted
-        for den, k in sorted(emitter.denominators.items(), key=lambda kv: kv[1]):
+        # (uniform entries divide uniform numerators: plain division, no hoisted divisor)
+        for den, k in sorted(emitter.denominators.items(), key=lambda kv: kv[1]) if only is None else ():
             lines += ["    const double tf_den%d = %s;" % (k, den),
                       "    const double tf_rden%d = 1.0 / tf_den%d;" % (k, k)]
-        lines += ["    %s[%d] = %s;" % (outname, i, e) for i, e in enumerate(exprs)]
+        lines += ["    %s[%d] = %s;" % (outname, i, e) for i, e in enumerate(exprs)
+                  if only is None or only[i]]
         return "\n".join(lines)
 
     def arr(name, values, ctype="int"):
@@ -289,6 +296,7 @@ def lower_model(model, parvec_mask=0, seg=8, sweep_block=64):
         "#define TF_USES_X %d" % (1 if uses_x else 0),
         arr("tf_pat_eq", pat_eq), arr("tf_pat_var", pat_var), arr("tf_pat_off", pat_off),
         arr("tf_par_is_vec", par_is_vec, "bool"),
+        arr("tf_j_uniform", j_uniform, "bool"),
         "TF_DEVICE void tf_eval_F(const double (&w)[TF_NVAR + TF_NH][2 * TF_MP + 1], "
         "const double* par, double dx, double xc, double* F) {",
         body("F", f_c, emit_f),
@@ -297,11 +305,16 @@ def lower_model(model, parvec_mask=0, seg=8, sweep_block=64):
         "const double* par, double dx, double xc, double* J) {",
         body("J", j_c, emit_j),
         "}",
+        "// the node-independent entries only (tf_j_uniform); same expressions, same bits",
+        "TF_DEVICE void tf_eval_J_uniform(const double* par, double dx, double* J) {",
+        "    const double xc = 0.0;",
+        body("J", j_c, emit_j, only=j_uniform),
+        "}",
         ""])
     spec = dict(nvar=nvar, nh=nh, npar=len(pars) + len(hc_list), npar_model=len(pars),
                 host_consts=hc_list, mp=mp, nnz=nnz, seg=seg,
                 sweep_block=sweep_block, uses_x=int(uses_x), parvec_mask=int(parvec_mask),
-                b2=mp * nvar, pat_eq=pat_eq, pat_var=pat_var, pat_off=pat_off,
+                b2=mp * nvar, pat_eq=pat_eq, pat_var=pat_var, pat_off=pat_off, j_uniform=j_uniform,
                 fields=fields, pars=pars)
     return src, spec
 

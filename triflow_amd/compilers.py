@@ -226,8 +226,8 @@ class HipBackend:
                 HipBackend._lib = Library(LIB_PATH)
             return HipBackend._lib
 
-    def load(self, model, parvec_mask, device=-1):
-        hsaco, spec = build_code_object(model, parvec_mask)
+    def load(self, model, parvec_mask, device=-1, seg=None):
+        hsaco, spec = build_code_object(model, parvec_mask, seg=seg)
         lib = self.library()
         is_dev, ndev = lib.runtime_info()
         if ndev < 1:
@@ -299,19 +299,31 @@ class CompiledModel:
         codegen.lower_model(model)
 
     # ---- code objects / solvers ------------------------------------------------
-    def device_model(self, parvec_mask=0, device=-1):
-        key = (parvec_mask, device)
+    @staticmethod
+    def sweep_segment(total_nodes):
+        """Nodes per thread of the stencil sweeps (TF_SEG): short segments when the grid has
+        too few chunks to fill the GPU otherwise (N = 1e6: spmv 43 -> 35 us, stage sweep 31 ->
+        27 us), the longer ones for big batches (8 members / N = 4e6: 1-2 % the other way)."""
+        if "TRIFLOW_SWEEP_SEG" in os.environ:
+            return int(os.environ["TRIFLOW_SWEEP_SEG"])
+        return 4 if total_nodes <= 2_000_000 else 8
+
+    def device_model(self, parvec_mask=0, device=-1, seg=None):
+        key = (parvec_mask, device, seg)
         if key not in self._device_models:
+            kw = {}
             if device >= 0:
-                self._device_models[key] = self.backend.load(self.model, parvec_mask, device)
-            else:
-                self._device_models[key] = self.backend.load(self.model, parvec_mask)
+                kw["device"] = device
+            if seg is not None:
+                kw["seg"] = seg          # (test back ends without the knob are never passed it)
+            self._device_models[key] = self.backend.load(self.model, parvec_mask, **kw)
         return self._device_models[key]
 
     def solver(self, N, periodic, nsys=1, parvec_mask=0, **opts):
         key = (int(N), bool(periodic), int(nsys), int(parvec_mask), tuple(sorted(opts.items())))
         if key not in self._solvers:
-            dm = self.device_model(parvec_mask, int(opts.get("device", -1)))
+            seg = self.sweep_segment(int(N) * int(nsys)) if isinstance(self.backend, HipBackend) else None
+            dm = self.device_model(parvec_mask, int(opts.get("device", -1)), seg)
             self._solvers[key] = DeviceSolver(dm, N, nsys=nsys, periodic=periodic, **opts)
         return self._solvers[key]
 

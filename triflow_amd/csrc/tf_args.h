@@ -58,6 +58,8 @@ struct TfSweepArgs {               // F / F+J stencil sweep, J @ v, A-row build
 
 struct TfSpmvArgs {                // y = scale * J @ v  (clamped/wrapped columns)
     TfLayout L;
+    const double* parsca;          // scalar parameters / dx: the node-independent Jacobian entries
+    const double* dx;              // are evaluated in the kernel, not read back (TfJUniform)
     const double* Jv;
     const double* v;               // [nvar] planes
     double* y;                     // [nvar] planes
@@ -83,6 +85,8 @@ struct TfNormArgs {               // per-variable, per-system norm of (a - b): p
 
 struct TfBerrArgs {               // componentwise backward error of (I - cJ) x = b
     TfLayout L;
+    const double* parsca;
+    const double* dx;
     const double* Jv;
     const double* x;               // [nvar] planes
     const double* rhs;             // [nvar] planes
@@ -135,8 +139,11 @@ struct TfPokeArgs {
 // explicit block-tridiagonal reduced system produced by the level below.
 struct TfLevelArgs {
     TfLayout L;
-    // level 1 matrix source
+    // level 1 matrix source: the Jacobian value planes; entries that do not depend on the node
+    // are evaluated from the scalar parameters instead of being read (TfJUniform)
     const double* Jv;
+    const double* parsca;
+    const double* dx;
     double c;
     // level >= 2 matrix source: [3][b][b] planes (sub, diag, super)
     const double* Ablk;

@@ -547,9 +547,6 @@ __device__ __forceinline__ void tfk_cr_factor_v3(const TfLevelArgs& a) {
             double* raL = row(aL, gq);
             double* raU = row(aU, gq);
             const int kLs = vL ? kL : 1, kRs = vR ? kR : 1;
-            double Lr[BB], Ur[BB];
-#pragma unroll
-            for (int m = 0; m < BB; ++m) { Lr[m] = raL[oL + m]; Ur[m] = raU[oU + m]; }
             constexpr bool YSEP = BB >= 8;
             const int hc = h < BB ? h : 0;
             const bool isy = !YSEP && h == BB;
@@ -562,15 +559,17 @@ __device__ __forceinline__ void tfk_cr_factor_v3(const TfLevelArgs& a) {
             }
             const int s0 = isy ? oY : oL + hc, s1 = isy ? oY : oU + hc;      // source columns of j = 0, 1
             double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, y0 = 0.0, y1 = 0.0;
+            // (the row's coupling entries are read where they are used, not kept: registers)
 #pragma unroll
             for (int m = 0; m < BB; ++m) {
                 const double* eL = row(kLs, m);
                 const double* eR = row(kRs, m);
-                a0 = tf_fma(-Lr[m], eL[s0], a0);
-                a1 = tf_fma(-Ur[m], eR[s1], a1);
-                a2 = tf_fma(-Lr[m], eL[oU + hc], a2);
-                a3 = tf_fma(-Ur[m], eR[oL + hc], a3);
-                if (YSEP) { y0 = tf_fma(-Lr[m], eL[oY], y0); y1 = tf_fma(-Ur[m], eR[oY], y1); }
+                const double lm = -raL[oL + m], um = -raU[oU + m];
+                a0 = tf_fma(lm, eL[s0], a0);
+                a1 = tf_fma(um, eR[s1], a1);
+                a2 = tf_fma(lm, eL[oU + hc], a2);
+                a3 = tf_fma(um, eR[oL + hc], a3);
+                if (YSEP) { y0 = tf_fma(lm, eL[oY], y0); y1 = tf_fma(um, eR[oY], y1); }
             }
             if (g < BB) {
                 if (h < BB) {

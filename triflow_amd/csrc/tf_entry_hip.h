@@ -196,7 +196,11 @@ __global__ void __launch_bounds__(64) tfk_top_solve(TfTopArgs a) { tfk_top_body<
 #define TF_CR_BLOCK (TF_B2 <= 2 ? 256 : 64)
 // the factorisation of 3 <= b <= 8: 8 wavefronts per chunk (version 3), else one
 #define TF_CR_FACTOR_BLOCK (TF_B2 <= 2 ? 256 : (TF_CR_V2 == 3 ? 512 : 64))
-__global__ void __launch_bounds__(TF_CR_FACTOR_BLOCK) tfk_cr_factor(TfLevelArgs a) {
+#ifndef TF_CR_FACTOR_WAVES
+#define TF_CR_FACTOR_WAVES 4       // wavefronts per SIMD the register allocator makes room for
+#endif
+__global__ void __attribute__((amdgpu_waves_per_eu(TF_CR_FACTOR_WAVES))) __launch_bounds__(TF_CR_FACTOR_BLOCK)
+tfk_cr_factor(TfLevelArgs a) {
     if constexpr (TF_B2 <= 2) tfk_crs_factor<TF_B2>(a);
     else if constexpr (TF_B2 <= 8) {
         if constexpr (TF_CR_V2 == 3) tfk_cr_factor_v3<TF_B2>(a);

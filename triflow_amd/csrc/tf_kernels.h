@@ -95,6 +95,26 @@ TF_DEVICE int64_t tf_next_x(const TfLevelArgs& a, int e, int p, int64_t s2, int 
     return a.next_aos ? (int64_t)(e * a.Lnext.N + p) * bn + k : (int64_t)k * a.Lnext.plane + s2;
 }
 
+// Jacobian entries that are the same at every node of a system (tf_j_uniform: constant
+// coefficients such as k/dx**2): the sweep stores them like every other entry of the
+// reference's value table, but the kernels that read the table back -- the solver walks, J @ v,
+// the backward-error monitor -- evaluate them once per thread from the scalar parameters,
+// with the very expressions of tf_eval_J (same bits), and only load the others.  Film model:
+// 10 of 19 entries are loaded, stiff model 11 of 24, scalar linear models none.
+#ifndef TF_USE_JUNIFORM
+#define TF_USE_JUNIFORM 1          // 0: read every entry back (A/B runs)
+#endif
+#define TF_JU(k) (TF_USE_JUNIFORM && tf_j_uniform[k])
+struct TfJUniform {
+    double v[TF_NNZ > 0 ? TF_NNZ : 1];
+    TF_DEVICE_M void init(const double* parsca, const double* dxp, int nsys, int e) {
+        double par[TF_NPAR > 0 ? TF_NPAR : 1];
+#pragma unroll
+        for (int k = 0; k < TF_NPAR; ++k) par[k] = tf_par_is_vec[k] ? 0.0 : parsca[k * nsys + e];
+        tf_eval_J_uniform(par, dxp[e], v);
+    }
+};
+
 // ===========================================================================
 // 1. F / F+J stencil sweep                       (compilers.py:227-332)
 // ===========================================================================
@@ -205,6 +225,8 @@ TF_DEVICE void tfk_spmv_body(const TfSpmvArgs& a, int pg, int seg) {
         for (int t = 1; t < a.nterms; ++t) acc = acc + a.vc[t] * a.vx[t][(int64_t)v * L.plane + s];
         return acc;
     };
+    TfJUniform ju;
+    ju.init(a.parsca, a.dx, L.nsys, e);
     double w[TF_NVAR][TF_W];
 #pragma unroll
     for (int v = 0; v < TF_NVAR; ++v)
@@ -226,7 +248,7 @@ TF_DEVICE void tfk_spmv_body(const TfSpmvArgs& a, int pg, int seg) {
             for (int v = 0; v < TF_NVAR; ++v) acc[v] = 0.0;
 #pragma unroll
             for (int k = 0; k < TF_NNZ; ++k) {       // pattern order = ascending column
-                double jv = a.scale * a.Jv[(int64_t)k * L.plane + s];
+                double jv = a.scale * (TF_JU(k) ? ju.v[k] : a.Jv[(int64_t)k * L.plane + s]);
                 double wv = w[tf_pat_var[k]][tf_pat_off[k] + TF_MP];
                 if (a.absval) { jv = tf_abs(jv); wv = tf_abs(wv); }
                 acc[tf_pat_eq[k]] = acc[tf_pat_eq[k]] + jv * wv;
@@ -258,6 +280,8 @@ TF_DEVICE double tfk_berr_body(const TfBerrArgs& a, int pg, int seg) {
     for (int v = 0; v < TF_NVAR; ++v)
 #pragma unroll
         for (int o = 1; o < TF_W; ++o) w[v][o] = ld(v, i0 - TF_MP + o - 1);
+    TfJUniform ju;
+    ju.init(a.parsca, a.dx, L.nsys, e);
     double worst = 0.0;
 #pragma unroll
     for (int j = 0; j < TF_SEG; ++j) {
@@ -275,7 +299,7 @@ TF_DEVICE double tfk_berr_body(const TfBerrArgs& a, int pg, int seg) {
             for (int v = 0; v < TF_NVAR; ++v) { acc[v] = 0.0; mag[v] = 0.0; }
 #pragma unroll
             for (int k = 0; k < TF_NNZ; ++k) {
-                const double jv = a.c * a.Jv[(int64_t)k * L.plane + s];
+                const double jv = a.c * (TF_JU(k) ? ju.v[k] : a.Jv[(int64_t)k * L.plane + s]);
                 const double wv = w[tf_pat_var[k]][tf_pat_off[k] + TF_MP];
                 acc[tf_pat_eq[k]] = acc[tf_pat_eq[k]] + jv * wv;
                 mag[tf_pat_eq[k]] = mag[tf_pat_eq[k]] + tf_abs(jv) * tf_abs(wv);
@@ -576,16 +600,19 @@ struct TfRowsL1 {
     static constexpr bool PIVOT = TF_NVAR == 1;
     const TfLevelArgs& a;
     int pg, e, p, len, start;
+    TfJUniform ju;                 // the node-independent entries: not read back
     TF_DEVICE_M TfRowsL1(const TfLevelArgs& a_, int pg_) : a(a_), pg(pg_) {
         e = pg / a.L.P; p = pg - e * a.L.P;
         len = tf_len(a.L, p); start = tf_start(a.L, p);
+        ju.init(a.parsca, a.dx, a.L.nsys, e);
     }
     // the values of one block row as they lie in memory; requested ahead of their use
     struct Raw { double jv[TF_NNZ > 0 ? TF_NNZ : 1]; };
     TF_DEVICE_M void request(int i, Raw& r) const {
         const int64_t s = tf_idx(a.L, pg, i);
 #pragma unroll
-        for (int k = 0; k < TF_NNZ; ++k) r.jv[k] = a.Jv[(int64_t)k * a.L.plane + s];
+        for (int k = 0; k < TF_NNZ; ++k)
+            r.jv[k] = TF_JU(k) ? ju.v[k] : a.Jv[(int64_t)k * a.L.plane + s];
     }
     TF_DEVICE_M void decode(int i, const Raw& raw, double (&row)[2 * TF_MP + 1][TF_NVAR][TF_NVAR]) const {
 #pragma unroll

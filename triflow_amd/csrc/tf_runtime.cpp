@@ -46,6 +46,9 @@ TfLayout make_layout(int nsys, int N, int P, int periodic) {
     L.Ptot = nsys * P;
     L.periodic = periodic;
     L.plane = (int64_t)L.M * L.Ptot;
+    // planes are spaced by `plane` elements; TRIFLOW_PLANE_PAD (elements) offsets consecutive
+    // planes against each other (experiments on HBM channel aliasing of the many-plane walks)
+    if (const char* v = getenv("TRIFLOW_PLANE_PAD")) L.plane += atoll(v);
     return L;
 }
 
@@ -295,6 +298,7 @@ struct tf_solver {
         TfSpmvArgs a;
         std::memset(&a, 0, sizeof(a));
         a.L = L1; a.Jv = Jv.p; a.v = v; a.y = y; a.scale = scale; a.absval = absval ? 1 : 0;
+        a.parsca = parsca.p; a.dx = dx.p;
         unsigned gx = cdiv(L1.Ptot, spec.sweep_block), gy = cdiv(L1.M, spec.seg);
         launch(TFK_SPMV, gx, gy, spec.sweep_block, &a, sizeof(a));
     }
@@ -305,6 +309,7 @@ struct tf_solver {
         TfSpmvArgs a;
         std::memset(&a, 0, sizeof(a));
         a.L = L1; a.Jv = Jv.p; a.v = nullptr; a.y = y; a.scale = 1.0;
+        a.parsca = parsca.p; a.dx = dx.p;
         a.nterms = nterms;
         for (int t = 0; t < nterms; ++t) { a.vx[t] = vx[t]; a.vc[t] = vc[t]; }
         a.addF = Fp; a.cF = cF; a.cA = cA;
@@ -328,7 +333,7 @@ struct tf_solver {
         Level& nx = next_of(l);
         TfLevelArgs a;
         std::memset(&a, 0, sizeof(a));
-        a.L = lv.L; a.Jv = Jv.p; a.c = factor_c; a.Ablk = lv.Ablk.p;
+        a.L = lv.L; a.Jv = Jv.p; a.parsca = parsca.p; a.dx = dx.p; a.c = factor_c; a.Ablk = lv.Ablk.p;
         a.rhs = l == 0 ? rhs1 : lv.rhs.p;
         a.x = l == 0 ? x1 : lv.x.p;
         a.Ut = lv.Ut.p; a.Et = lv.Et.p; a.yt = lv.yt.p; a.Dinv = lv.Dinv.p; a.Unup = lv.Unup.p;
@@ -427,6 +432,7 @@ struct tf_solver {
         tfb::memset0(red.p, sizeof(double), stream);
         TfBerrArgs a;
         a.L = L1; a.Jv = Jv.p; a.x = x1; a.rhs = rhs1; a.c = factor_c; a.red = red.p;
+        a.parsca = parsca.p; a.dx = dx.p;
         unsigned gx = cdiv(L1.Ptot, spec.sweep_block), gy = cdiv(L1.M, spec.seg);
         launch(TFK_BERR, gx, gy, spec.sweep_block, &a, sizeof(a));
         double h = 0;

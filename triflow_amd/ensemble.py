@@ -63,7 +63,9 @@ class Ensemble:
         # a solver of its own (not the per-shape cache of CompiledModel.solver): two ensembles
         # of the same shape must not share state slots, parameters or boundary data
         from ._capi import DeviceSolver
-        self.solver = DeviceSolver(cm.device_model(mask, int(device)), self.N, nsys=self.nsys,
+        from .compilers import HipBackend
+        seg = cm.sweep_segment(self.N * self.nsys) if isinstance(cm.backend, HipBackend) else None
+        self.solver = DeviceSolver(cm.device_model(mask, int(device), seg), self.N, nsys=self.nsys,
                                    periodic=periodic, device=device, **solver_opts)
         s = self.solver
         s.set_dx((x[:, -1] - x[:, 0]) / (self.N - 1))
