@@ -260,6 +260,10 @@ def main():
         stages = len(ens.tab.b) if ens.tab is not None else 1
         bytes_per_launch = sweep_bytes_per_node(model) * N * len(mine)
         achieved = bytes_per_launch / (sweep_ms / sweep_n * 1e-3) / 1e9 if sweep_n else None
+        # Theta / BDF-2 run the sweep fused with their right-hand side: the kernel also writes
+        # rhs (8*nvar) and, for BDF-2, reads and rewrites the history U_{n-1} (16*nvar)
+        fused_extra = {"tfk_sweep_fj_theta": 8, "tfk_sweep_fj_bdf2": 24}.get(sweep_kernel, 0) * model._nvar
+        fused_bytes = (sweep_bytes_per_node(model) + fused_extra) * N * len(mine)
         step_bytes = step_bytes_per_node(model, scheme, stages) * N * len(mine)
         step_gbs = step_bytes / elapsed * args.steps / 1e9
         traffic, traffic_src = None, None
@@ -299,6 +303,11 @@ def main():
                               "formula": "SURVEY 8(d) implicit-step bytes: %d B/node" %
                                          step_bytes_per_node(model, scheme, stages)},
         }
+        if fused_extra and sweep_n:
+            out["roofline"]["fused_bytes_per_launch"] = fused_bytes
+            out["roofline"]["fused_frac"] = fused_bytes / (sweep_ms / sweep_n * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["roofline"]["fused_note"] = ("%s = F+J sweep + the scheme's right-hand side in one pass: 'frac' prices it by "
+                                             "SURVEY's F+J formula, 'fused_frac' by the bytes it moves" % sweep_kernel)
         if report:
             out["kernels_ms_per_step"] = {k: round(v[0] / nprof, 5) for k, v in report.items()}
         if world > 1:

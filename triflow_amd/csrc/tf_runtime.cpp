@@ -201,6 +201,16 @@ struct tf_solver {
         stamps.clear();
     }
     static unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+    // grid.x of the stencil sweeps (grid.y = segments along the chunks).  Workgroups are dealt
+    // round robin over the 8 XCDs in linear order (id = y * gx + x): with gx a multiple of 8
+    // the segments above and below a workgroup -- whose first / last rows are its ghost rows --
+    // run on the same XCD, and the re-read of those rows is served by that XCD's L2 instead of
+    // crossing to the memory side (the extra workgroups find pg >= Ptot and leave).
+    unsigned sweep_gx() const {
+        const unsigned gx = cdiv(L1.Ptot, spec.sweep_block);
+        static const bool xcd = getenv("TRIFLOW_XCD_GRID") ? atoi(getenv("TRIFLOW_XCD_GRID")) != 0 : true;
+        return (xcd && gx > 8) ? (gx + 7u) / 8u * 8u : gx;
+    }
 
     // ------------------------------------------------------ elementary steps
     void vec(int op, double* out, const double* base, int nterms, const double* const* xs,
@@ -264,7 +274,7 @@ struct tf_solver {
         for (int t = 0; t < nterms; ++t) { a.kx[t] = kx[t]; a.kc[t] = kc[t]; }
         a.L = L1; a.fields = fields; a.helpers = helpers.p; a.parvec = parvec.p; a.parsca = parsca.p;
         a.dx = dx.p; a.xcoord = xcoord.p; a.F = F.p; a.Jv = Jv.p; a.with_j = with_j ? 1 : 0;
-        unsigned gx = cdiv(L1.Ptot, spec.sweep_block), gy = cdiv(L1.M, spec.seg);
+        unsigned gx = sweep_gx(), gy = cdiv(L1.M, spec.seg);
         if (nterms > 0 && with_j) throw std::logic_error("stage sweep evaluates F only");
         launch(with_j ? TFK_SWEEP_FJ : (nterms > 0 ? TFK_SWEEP_F_STAGE : TFK_SWEEP_F), gx, gy,
                spec.sweep_block, &a, sizeof(a));
@@ -278,7 +288,7 @@ struct tf_solver {
         a.L = L1; a.fields = fields; a.helpers = helpers.p; a.parvec = parvec.p; a.parsca = parsca.p;
         a.dx = dx.p; a.xcoord = xcoord.p; a.F = F.p; a.Jv = Jv.p; a.with_j = 1;
         a.bdf_rhs = rhs; a.bdf_prev = prev; a.bdf_c0 = c0; a.bdf_c1 = c1; a.bdf_two_step = two_step ? 1 : 0;
-        unsigned gx = cdiv(L1.Ptot, spec.sweep_block), gy = cdiv(L1.M, spec.seg);
+        unsigned gx = sweep_gx(), gy = cdiv(L1.M, spec.seg);
         launch(TFK_SWEEP_FJ_BDF2, gx, gy, spec.sweep_block, &a, sizeof(a));
         have_jac = true; have_factor = false;
     }
@@ -290,7 +300,7 @@ struct tf_solver {
         a.L = L1; a.fields = fields; a.helpers = helpers.p; a.parvec = parvec.p; a.parsca = parsca.p;
         a.dx = dx.p; a.xcoord = xcoord.p; a.F = F.p; a.Jv = Jv.p; a.with_j = 1;
         a.theta_rhs = rhs; a.theta = theta; a.theta_dt = dt;
-        unsigned gx = cdiv(L1.Ptot, spec.sweep_block), gy = cdiv(L1.M, spec.seg);
+        unsigned gx = sweep_gx(), gy = cdiv(L1.M, spec.seg);
         launch(TFK_SWEEP_FJ_THETA, gx, gy, spec.sweep_block, &a, sizeof(a));
         have_jac = true; have_factor = false;
     }
@@ -299,7 +309,7 @@ struct tf_solver {
         std::memset(&a, 0, sizeof(a));
         a.L = L1; a.Jv = Jv.p; a.v = v; a.y = y; a.scale = scale; a.absval = absval ? 1 : 0;
         a.parsca = parsca.p; a.dx = dx.p;
-        unsigned gx = cdiv(L1.Ptot, spec.sweep_block), gy = cdiv(L1.M, spec.seg);
+        unsigned gx = sweep_gx(), gy = cdiv(L1.M, spec.seg);
         launch(TFK_SPMV, gx, gy, spec.sweep_block, &a, sizeof(a));
     }
 
@@ -313,7 +323,7 @@ struct tf_solver {
         a.nterms = nterms;
         for (int t = 0; t < nterms; ++t) { a.vx[t] = vx[t]; a.vc[t] = vc[t]; }
         a.addF = Fp; a.cF = cF; a.cA = cA;
-        unsigned gx = cdiv(L1.Ptot, spec.sweep_block), gy = cdiv(L1.M, spec.seg);
+        unsigned gx = sweep_gx(), gy = cdiv(L1.M, spec.seg);
         launch(TFK_SPMV, gx, gy, spec.sweep_block, &a, sizeof(a));
     }
 
@@ -433,7 +443,7 @@ struct tf_solver {
         TfBerrArgs a;
         a.L = L1; a.Jv = Jv.p; a.x = x1; a.rhs = rhs1; a.c = factor_c; a.red = red.p;
         a.parsca = parsca.p; a.dx = dx.p;
-        unsigned gx = cdiv(L1.Ptot, spec.sweep_block), gy = cdiv(L1.M, spec.seg);
+        unsigned gx = sweep_gx(), gy = cdiv(L1.M, spec.seg);
         launch(TFK_BERR, gx, gy, spec.sweep_block, &a, sizeof(a));
         double h = 0;
         tfb::d2h(&h, red.p, sizeof(h), stream);
