@@ -82,7 +82,7 @@ def build_runtime_library(force=False):
         return LIB_PATH
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
     cmd = [_hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "--offload-arch=" + GPU_ARCH,
-           "-I", CSRC, *srcs, "-o", LIB_PATH + ".tmp"]
+           "-I", CSRC, *srcs, "-lpthread", "-o", LIB_PATH + ".tmp"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("building libtriflow_hip.so failed:\n" + res.stderr[-4000:])

@@ -5,8 +5,11 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <thread>
 #include <stdexcept>
 #include <string>
 
@@ -52,13 +55,87 @@ void* dev_alloc(size_t bytes) {
 }
 void dev_free(void* p) { if (p) (void)hipFree(p); }
 void memset0(void* p, size_t bytes, Stream* s) { TF_HIP(hipMemsetAsync(p, 0, bytes, s->s)); }
+// Host <-> device copies of the drop-in path (model.F / model.J: NumPy arrays in and out).  A
+// copy from / to pageable memory is staged by the runtime in small pieces; large transfers go
+// through two page-locked bounce buffers of our own instead: the CPU fills (or drains) one
+// with several threads while the DMA engine moves the other.
+namespace {
+constexpr size_t kStageChunk = 8u << 20;        // bytes per bounce buffer
+constexpr size_t kStageMin = 4u << 20;          // smaller transfers: plain hipMemcpyAsync
+struct Bounce {
+    void* buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2];
+    bool ok = false;
+    Bounce() {
+        if (hipHostMalloc(&buf[0], kStageChunk, hipHostMallocDefault) != hipSuccess) return;
+        if (hipHostMalloc(&buf[1], kStageChunk, hipHostMallocDefault) != hipSuccess) return;
+        if (hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess) return;
+        if (hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess) return;
+        ok = true;
+    }
+};
+Bounce& bounce() { static thread_local Bounce b; return b; }
+void parallel_copy(void* dst, const void* src, size_t n) {
+    constexpr int NT = 4;
+    if (n < (1u << 20)) { std::memcpy(dst, src, n); return; }
+    std::thread th[NT - 1];
+    const size_t part = (n / NT + 63) & ~(size_t)63;
+    for (int t = 1; t < NT; ++t) {
+        const size_t lo = std::min(n, part * t), hi = std::min(n, part * (t + 1));
+        th[t - 1] = std::thread([=] { if (hi > lo) std::memcpy((char*)dst + lo, (const char*)src + lo, hi - lo); });
+    }
+    std::memcpy(dst, src, std::min(n, part));
+    for (int t = 1; t < NT; ++t) th[t - 1].join();
+}
+}  // namespace
 void h2d(void* dst, const void* src, size_t bytes, Stream* s) {
-    TF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s->s));
+    Bounce& b = bounce();
+    if (bytes < kStageMin || !b.ok) {
+        TF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s->s));
+        TF_HIP(hipStreamSynchronize(s->s));
+        return;
+    }
+    size_t off = 0;
+    for (int k = 0; off < bytes; ++k) {
+        const int i = k & 1;
+        const size_t n = std::min(kStageChunk, bytes - off);
+        if (k >= 2) TF_HIP(hipEventSynchronize(b.ev[i]));           // the DMA out of this buffer is done
+        parallel_copy(b.buf[i], (const char*)src + off, n);
+        TF_HIP(hipMemcpyAsync((char*)dst + off, b.buf[i], n, hipMemcpyHostToDevice, s->s));
+        TF_HIP(hipEventRecord(b.ev[i], s->s));
+        off += n;
+    }
     TF_HIP(hipStreamSynchronize(s->s));
 }
 void d2h(void* dst, const void* src, size_t bytes, Stream* s) {
-    TF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s->s));
-    TF_HIP(hipStreamSynchronize(s->s));
+    Bounce& b = bounce();
+    if (bytes < kStageMin || !b.ok) {
+        TF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s->s));
+        TF_HIP(hipStreamSynchronize(s->s));
+        return;
+    }
+    size_t off = 0, done = 0;
+    int k = 0;
+    for (; off < bytes; ++k) {
+        const int i = k & 1;
+        const size_t n = std::min(kStageChunk, bytes - off);
+        if (k >= 2) {                                              // drain the chunk that used this buffer
+            TF_HIP(hipEventSynchronize(b.ev[i]));
+            const size_t m = std::min(kStageChunk, bytes - done);
+            parallel_copy((char*)dst + done, b.buf[i], m);
+            done += m;
+        }
+        TF_HIP(hipMemcpyAsync(b.buf[i], (const char*)src + off, n, hipMemcpyDeviceToHost, s->s));
+        TF_HIP(hipEventRecord(b.ev[i], s->s));
+        off += n;
+    }
+    for (int j = (k >= 2 ? k - 2 : 0); j < k; ++j) {               // the last one or two chunks
+        const int i = j & 1;
+        TF_HIP(hipEventSynchronize(b.ev[i]));
+        const size_t m = std::min(kStageChunk, bytes - done);
+        parallel_copy((char*)dst + done, b.buf[i], m);
+        done += m;
+    }
 }
 void d2d(void* dst, const void* src, size_t bytes, Stream* s) {
     TF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s->s));
