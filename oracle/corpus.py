@@ -43,7 +43,18 @@ MODELS = {
     "euler_const": ("k * dxxU + E * U + pi * dxU", "U", "k", None),
 }
 
+#: models without reference goldens: only used to exercise the banded solver at block sizes the
+#: corpus above does not reach (b = mp * nvar = 3, 4, 7), against SuperLU on the oracle's Jacobian
+SOLVER_MODELS = {
+    "tri3": (["k*dxx%s + %s*dx%s - %s" % (v, w, v, v) for v, w in zip("ABC", "BCA")], list("ABC"), "k", None),
+    "quad4": (["k*dxx%s + %s*dx%s" % (v, w, v) for v, w in zip("ABCD", "BCDA")], list("ABCD"), "k", None),
+    "pair4": (["-dxxxxA + k*dxxA + B*dxA", "k*dxxB - A*dxxxB"], ["A", "B"], "k", None),
+    "seven": (["k*dxx%s + %s*dx%s" % (v, w, v) for v, w in zip("ABCDGHK", "BCDGHKA")], list("ABCDGHK"), "k", None),
+}
+MODELS_ALL = dict(MODELS, **SOLVER_MODELS)
+
 DEFAULT_PARS = {
+    "tri3": dict(k=.2), "quad4": dict(k=.2), "pair4": dict(k=.3), "seven": dict(k=.2),
     "M1_advdiff": dict(k=.001, c=.03),
     "M2_diff": dict(k=1e-3), "diff_nested": dict(k=1e-3), "diff_list": dict(k=1e-3),
     "heat_nopar": {},
@@ -63,12 +74,12 @@ DEFAULT_PARS = {
 
 
 def model_args(name):
-    eqs, dep, pars, helps = MODELS[name]
+    eqs, dep, pars, helps = MODELS_ALL[name]
     return (eqs, dep, pars, helps)
 
 
 def field_names(name):
-    eqs, dep, pars, helps = MODELS[name]
+    eqs, dep, pars, helps = MODELS_ALL[name]
     as_list = lambda a: [] if a is None else ([a] if isinstance(a, str) else list(a))
     return as_list(dep), as_list(helps), as_list(pars)
 

@@ -50,6 +50,16 @@ def test_linear_solve_small(name):
     pc.check_linear_solve(name, HIP, 203, plans, tol=tol)
 
 
+@pytest.mark.parametrize("name", sorted(corpus.SOLVER_MODELS))
+def test_linear_solve_block_sizes(name):
+    """Block sizes of the reduced levels that the corpus does not reach: b = mp * nvar = 3
+    (tri3), 4 (quad4: 4 variables, pair4: 2 variables with 5-point stencils), 7 (seven) -- each
+    its own instantiation of the cooperative kernels; refinement off."""
+    pc.check_linear_solve(name, HIP, 203, [dict(refine=0), dict(refine=0, m1=8, m_upper=4)],
+                          tol=1e-7 if name == "pair4" else 1e-9)
+    pc.check_linear_solve(name, HIP, 5003, [dict(refine=0, m1=8)], tol=1e-6 if name == "pair4" else 1e-8)
+
+
 @pytest.mark.parametrize("name", ["M3_film", "M5_stiff", "wide4", "six", "bivar"])
 def test_factorisation_is_accurate_without_refinement(name):
     """The automatic refinement must not be what makes a solve right: with it switched

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 from oracle import corpus
 from triflow_amd import Model, compilers
 
-for name in sorted(corpus.MODELS):
+for name in sorted(corpus.MODELS_ALL):
     t = time.time()
     m = Model(*corpus.model_args(name), compiler=lambda m: (None, None))
     for mask in (0,):
