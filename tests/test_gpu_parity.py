@@ -279,21 +279,20 @@ def test_config4_shard_full_size():
         out1 = ens1.state()[:, 0, :]
         ens1.close()
         return out1
-    # (a) the same level plan as the batch (its reduced levels are sized by all members
-    # together: chunk walks above 40 000 nodes): the batch dimension only
-    # adds chunks to the same kernels, member 3 comes out bit for bit
-    os.environ["TRIFLOW_CR_MAX_NODES"] = "5000"
-    try:
-        same_plan = run(member())
-    finally:
-        del os.environ["TRIFLOW_CR_MAX_NODES"]
-    assert np.array_equal(same_plan, out[:, e, :])
-    # (b) the plan a single member gets by default (cyclic reduction on every reduced level):
+    # (a) the plan a single member gets by default is the batch's plan (chunk counts do not
+    # depend on the number of members): the batch dimension only adds chunks to the same
+    # kernels, member 3 comes out bit for bit
+    assert np.array_equal(run(member()), out[:, e, :])
+    # (b) another level plan (chunk walks instead of cyclic reduction above 5000 nodes):
     # another elimination order of a matrix with cond(I - gamma dt J) = 2e10,
     # so the two backward-stable solves differ by cond * eps; measured 2.8e-10, bound 100 x
-    ref = run(member())
+    os.environ["TRIFLOW_CR_MAX_NODES"] = "5000"
+    try:
+        ref = run(member())
+    finally:
+        del os.environ["TRIFLOW_CR_MAX_NODES"]
     err = np.abs(ref - out[:, e, :]).max() / np.abs(ref).max()
-    print("config 4 shard: member %d vs single-member solver (default plan) %.1e" % (e, err))
+    print("config 4 shard: member %d vs single-member solver (walk plan) %.1e" % (e, err))
     assert err <= 3e-8, err
 
 

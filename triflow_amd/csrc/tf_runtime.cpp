@@ -587,14 +587,16 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
     }
     m1 = std::max(m1, 2 * sp.mp);
     {
-        // Cyclic reduction pays where a level is latency-bound (few chunks): one wavefront
-        // per 16-node chunk does about twice the arithmetic of the walks (later rounds leave
-        // lanes idle).  Levels with more nodes than cr_max_nodes (all ensemble members
-        // together; ~10 wavefronts per CU, scanned with tools/gpu_cr_scan.sh) keep the walks.
-        // (scalar models, b <= 2: one thread per node, chunks of 256, no such limit)
+        // Reduced levels: cyclic reduction inside 16-node chunks wherever the back end has the
+        // kernels for this block size (b <= 8).  Round 1 kept the chunk walks (tfk_bt_*) for levels
+        // above 40 000 nodes, where its one-wavefront-per-chunk factorisation lost to them; with a
+        // wavefront per node (tf_cr2_hip.h) cyclic reduction wins there too (config 5: 507 -> 524
+        // steps/s, 8 members per GPU: 1897 -> 1983; profiles/r02_ab_runs.txt, r2v).  The walks
+        // serve b > 8, the host emulation, and TRIFLOW_CR_MAX_NODES=<n> for comparisons.
+        // (scalar models, b <= 2: one thread per node, chunks of 256)
         const int cr_cap = b2 <= 2 ? TF_CRS_MAXLEN : TF_CR_MAXLEN;
         const int cr_len = opts && opts->m_upper > 0 ? std::min(std::max(opts->m_upper, 2), cr_cap) : cr_cap;
-        int64_t cr_max_nodes = b2 <= 2 ? ((int64_t)1 << 40) : 40000;
+        int64_t cr_max_nodes = (int64_t)1 << 40;
         if (const char* v = getenv("TRIFLOW_CR_MAX_NODES")) cr_max_nodes = atoll(v);
         int n = (int)N, B = sp.nvar, MP = sp.mp, m = m1;
         bool first = true;
