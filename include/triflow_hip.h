@@ -176,7 +176,7 @@ int tf_sync(tf_solver*);            /* waits for the stream, reports device-side
 
 /* ---- measurement: kernel begin/end timestamps (HIP events attached to the
  * launch) per kernel; mask bit k selects kernel k, -1 = all, 0 = off ---------- */
-int tf_timing_enable(tf_solver*, int32_t mask);
+int tf_timing_enable(tf_solver*, int64_t mask);
 int tf_timing_reset(tf_solver*);
 int tf_timing_get(tf_solver*, int32_t kernel, double* total_ms, int64_t* launches);
 /* diagnostic kernel builds (-DTF_STAMPS): shader-clock stamps of one workgroup per solver

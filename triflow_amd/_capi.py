@@ -80,7 +80,7 @@ SIGNATURES = {
                                    C.c_int32, C.c_int32, C.POINTER(Scheme), C.c_int32, c_double_p]),
     "tf_backward_error": (C.c_int, [C.c_void_p, c_double_p, c_int32_p]),
     "tf_sync": (C.c_int, [C.c_void_p]),
-    "tf_timing_enable": (C.c_int, [C.c_void_p, C.c_int32]),
+    "tf_timing_enable": (C.c_int, [C.c_void_p, C.c_int64]),
     "tf_timing_reset": (C.c_int, [C.c_void_p]),
     "tf_timing_get": (C.c_int, [C.c_void_p, C.c_int32, c_double_p, c_int64_p]),
     "tf_debug_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int32]),

@@ -131,9 +131,18 @@ struct tf_solver {
     // the backward-error check is a monitor: every factorisation while the matrix is new
     // (first 4, or c changed by > 10 %), then every berr_every-th one
     int berr_every = 8;
-    int64_t n_factor = 0, last_checked = -1000;
-    double checked_c = 0.0;
+    int64_t n_factor = 0;
     bool check_now = true;
+    // verdicts of the checked factorisations by value of c (within 10 %): a controller that
+    // alternates between two step sizes (step doubling: coarse m*dt, fine dt) does not trigger
+    // a synchronising check at every switch
+    struct Checked { double c; int sweeps; int64_t at; };
+    std::vector<Checked> checked;
+    Checked* checked_like(double c) {
+        for (auto& e : checked)
+            if (std::fabs(c - e.c) <= 0.1 * std::fabs(e.c)) return &e;
+        return nullptr;
+    }
 
     // declarative Dirichlet hook
     int ndir = 0;
@@ -151,7 +160,7 @@ struct tf_solver {
     std::map<int64_t, std::unique_ptr<BdfHist>> bdf_owned;
 
     // timing
-    uint32_t timing = 0;     // bit k: time launches of kernel k
+    uint64_t timing = 0;     // bit k: time launches of kernel k
     struct Stamp { int kernel; tfb::Event *a, *b; };
     std::vector<Stamp> stamps;
     std::vector<tfb::Event*> event_pool;
@@ -181,7 +190,7 @@ struct tf_solver {
         return tfb::event_create();
     }
     void launch(int kernel, unsigned gx, unsigned gy, unsigned block, const void* args, size_t sz) {
-        if ((timing >> kernel) & 1u) {
+        if ((timing >> kernel) & 1ull) {
             Stamp stp{kernel, get_event(), get_event()};
             tfb::launch_timed(model->module, kernel, gx, gy, block, args, sz, stream, stp.a, stp.b);
             stamps.push_back(stp);
@@ -395,10 +404,11 @@ struct tf_solver {
         if (!fold_top()) { TfTopArgs t = top_args(); launch(TFK_TOP_FACTOR, cdiv((int64_t)nsys * (tfb::coop_group(top.B) == 8 ? 8 : 1), 64), 1, 64, &t, sizeof(t)); }
         have_factor = true;
         ++n_factor;
-        const bool c_moved = std::fabs(c - checked_c) > 0.1 * std::fabs(checked_c);
-        check_now = n_factor <= 4 || c_moved || n_factor - last_checked >= berr_every;
+        const Checked* like = checked_like(c);
+        check_now = n_factor <= 4 || !like || n_factor - like->at >= berr_every;
         if (check_now) { fact_checked = false; fact_needs_refine = false; sweeps_needed = 0; }
-        // (between checks the verdict of the last checked factorisation stands)
+        else { sweeps_needed = like->sweeps; fact_needs_refine = sweeps_needed > 0; }
+        // (between checks the verdict of the last checked factorisation with such a c stands)
         if (rhs1 == nullptr) return;
         if (!fused) { solve(rhs1, x1); return; }
         if (!fold_top()) { TfTopArgs t = top_args(); launch(TFK_TOP_SOLVE, cdiv(nsys, 64), 1, 64, &t, sizeof(t)); }
@@ -472,8 +482,7 @@ struct tf_solver {
             if (!fact_checked) {
                 last_omega = backward_error(rhs1, x1);
                 fact_checked = true;
-                last_checked = n_factor;
-                checked_c = factor_c;
+                // (recorded below, once the number of sweeps is known)
                 sweeps_needed = 0;
                 if (!(last_omega <= refine_trigger)) {
                     // polish down to 1e-13 (or until it stops improving), at most 6 sweeps
@@ -488,6 +497,11 @@ struct tf_solver {
                 }
                 fact_needs_refine = sweeps_needed > 0;
                 if (!(last_omega <= 1e-6)) unstable = true;
+                if (Checked* e = checked_like(factor_c)) { e->c = factor_c; e->sweeps = sweeps_needed; e->at = n_factor; }
+                else {
+                    if (checked.size() >= 4) checked.erase(checked.begin());
+                    checked.push_back(Checked{factor_c, sweeps_needed, n_factor});
+                }
             } else {
                 for (int it = 0; it < sweeps_needed; ++it) refine_sweep(rhs1, x1);
             }
@@ -878,7 +892,7 @@ int tf_eval(tf_solver* s, int32_t slot, int32_t with_j) {
 int tf_eval_repeat(tf_solver* s, int32_t slot, int32_t with_j, int32_t reps, double* total_ms) {
     TF_API_BEGIN
     require(s && total_ms && reps >= 1, "tf_eval_repeat: arguments");
-    const uint32_t saved = s->timing;
+    const uint64_t saved = s->timing;
     s->timing = 0;
     tfb::Event* a = s->get_event();
     tfb::Event* b = s->get_event();
@@ -1167,11 +1181,11 @@ int tf_sync(tf_solver* s) {
 }
 
 // ------------------------------------------------------------- measurement
-int tf_timing_enable(tf_solver* s, int32_t on) {
+int tf_timing_enable(tf_solver* s, int64_t on) {
     TF_API_BEGIN
     require(s, "null solver");
     s->collect_timing();
-    s->timing = on < 0 ? 0xffffffffu : (uint32_t)on;
+    s->timing = on < 0 ? ~0ull : (uint64_t)on;
     TF_API_END
 }
 int tf_timing_reset(tf_solver* s) {
