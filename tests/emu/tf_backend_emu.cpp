@@ -43,6 +43,13 @@ void module_unload(Module* m) { delete m; }
 Stream* stream_create() { return new Stream(); }
 void stream_destroy(Stream* s) { delete s; }
 void stream_sync(Stream*) {}
+struct Graph { int dummy; };
+bool graphs_supported() { return false; }
+void capture_begin(Stream*) {}
+Graph* capture_end(Stream*) { return nullptr; }
+void capture_abort(Stream*) {}
+void graph_launch(Graph*, Stream*) {}
+void graph_destroy(Graph*) {}
 Event* event_create() { return new Event(); }
 void event_destroy(Event* e) { delete e; }
 void event_record(Event*, Stream*) {}

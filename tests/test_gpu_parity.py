@@ -304,6 +304,32 @@ def test_fused_step_doubling():
     pc.check_fused_step_doubling(HIP)
 
 
+def test_graph_replay_equals_eager():
+    """Fixed steps of small grids are captured into HIP graphs and replayed (tf_solver::run_graphed):
+    the same launches, so the same bits as issuing them one by one -- Theta with a Dirichlet hook,
+    ROS2 and RODASPR (fixed step) -- and a change of dt or of the boundary values is honoured."""
+    import os
+    from triflow_amd.ensemble import Ensemble
+    cases = [(1, "Theta", pc.DEVICE_HOOKS["cfg1"]), (3, "ROS2", None), (3, "RODASPR", None)]
+    for cfg, sch, hook in cases:
+        name, fd, pars, dt, _ = corpus.config_inputs(cfg, 200 if cfg == 1 else 3000)
+        m = pc.device_model(name, HIP)
+        fields = {k: v[None, :] for k, v in fd.items() if k != "x"}
+        out = []
+        for graphs in ("1", "0"):
+            os.environ["TRIFLOW_GRAPHS"] = graphs
+            try:
+                ens = Ensemble(m, fd["x"], fields, pars, bool(pars["periodic"]), scheme=sch, hook=hook, nstate=2)
+            finally:
+                del os.environ["TRIFLOW_GRAPHS"]
+            for k in range(30):
+                ens.step(dt if k < 20 else 0.5 * dt)          # the last ten with another step size
+            ens.sync()
+            out.append(ens.state().copy())
+            ens.close()
+        assert np.isfinite(out[0]).all() and np.array_equal(out[0], out[1]), (cfg, sch)
+
+
 def test_time_dependent_hook():
     pc.check_time_dependent_hook(HIP)
 

@@ -45,6 +45,16 @@ void launch(Module* m, int kernel, unsigned gx, unsigned gy, unsigned block,
 void launch_timed(Module* m, int kernel, unsigned gx, unsigned gy, unsigned block,
                   const void* args, size_t arg_bytes, Stream* s, Event* start, Event* stop);
 
+// Stream capture into an executable graph (HIP graphs): a step of a small problem is a string of
+// launch-bound kernels, replayed with one call.  The emulation has none (graphs_supported()).
+struct Graph;
+bool graphs_supported();
+void capture_begin(Stream* s);
+Graph* capture_end(Stream* s);               // ends the capture, instantiates
+void capture_abort(Stream* s);
+void graph_launch(Graph* g, Stream* s);
+void graph_destroy(Graph* g);
+
 Event* event_create();
 void event_destroy(Event* e);
 void event_record(Event* e, Stream* s);

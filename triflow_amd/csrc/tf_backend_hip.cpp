@@ -209,6 +209,30 @@ void launch_timed(Module* m, int kernel, unsigned gx, unsigned gy, unsigned bloc
                                     nullptr, config, start->e, stop->e, 0));
 }
 
+struct Graph { hipGraph_t graph; hipGraphExec_t exec; };
+bool graphs_supported() { return true; }
+void capture_begin(Stream* s) { TF_HIP(hipStreamBeginCapture(s->s, hipStreamCaptureModeThreadLocal)); }
+Graph* capture_end(Stream* s) {
+    hipGraph_t graph = nullptr;
+    TF_HIP(hipStreamEndCapture(s->s, &graph));
+    hipGraphExec_t exec = nullptr;
+    hipError_t err = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (err != hipSuccess) { (void)hipGraphDestroy(graph); check(err, "hipGraphInstantiate"); }
+    return new Graph{graph, exec};
+}
+void capture_abort(Stream* s) {
+    hipGraph_t graph = nullptr;
+    (void)hipStreamEndCapture(s->s, &graph);
+    if (graph) (void)hipGraphDestroy(graph);
+}
+void graph_launch(Graph* g, Stream* s) { TF_HIP(hipGraphLaunch(g->exec, s->s)); }
+void graph_destroy(Graph* g) {
+    if (!g) return;
+    (void)hipGraphExecDestroy(g->exec);
+    (void)hipGraphDestroy(g->graph);
+    delete g;
+}
+
 Event* event_create() {
     Event* e = new Event();
     TF_HIP(hipEventCreate(&e->e));

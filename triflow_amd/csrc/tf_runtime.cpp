@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -159,6 +160,61 @@ struct tf_solver {
     BdfHist bdf0;
     std::map<int64_t, std::unique_ptr<BdfHist>> bdf_owned;
 
+    // A fixed step is a fixed string of launches: captured once per (scheme, slots, dt, ...)
+    // into a HIP graph and replayed.  Worth it where a step is launch-bound (small grids: ~24
+    // launches of a few microseconds, the host cannot issue them faster than they run), so on
+    // by default up to 5e4 nodes (ROS2, N = 200 ... 2000: +11 ... 15 %, Theta: none); TRIFLOW_GRAPHS=0 / 1
+    // forces it.  While a graph is captured
+    // (TF_CAPTURE) the step function runs as usual, the launches are recorded instead of
+    // executed; on a replay it runs "dry" (TF_DRY: the host-side bookkeeping -- factorisation
+    // counters, flags -- without the launches) and the graph is launched.
+    enum LaunchMode { TF_EAGER = 0, TF_CAPTURE, TF_DRY };
+    LaunchMode mode = TF_EAGER;
+    bool graphs_on = false;
+    struct GraphEntry { tfb::Graph* graph; int64_t used; };
+    std::map<std::string, GraphEntry> graphs;
+    int64_t graph_clock = 0, graph_replays = 0;
+    void drop_graphs() {
+        for (auto& kv : graphs) tfb::graph_destroy(kv.second.graph);
+        graphs.clear();
+    }
+    template <class Fn> void run_graphed(const std::string& key, bool graphable, Fn fn) {
+        if (!graphs_on || !graphable || timing != 0) { fn(); return; }
+        auto it = graphs.find(key);
+        if (it == graphs.end()) {
+            tfb::capture_begin(stream);
+            mode = TF_CAPTURE;
+            try { fn(); } catch (...) { mode = TF_EAGER; tfb::capture_abort(stream); throw; }
+            mode = TF_EAGER;
+            tfb::Graph* g = tfb::capture_end(stream);
+            if (graphs.size() >= 8) {                               // least recently used goes
+                auto victim = graphs.begin();
+                for (auto jt = graphs.begin(); jt != graphs.end(); ++jt)
+                    if (jt->second.used < victim->second.used) victim = jt;
+                tfb::graph_destroy(victim->second.graph);
+                graphs.erase(victim);
+            }
+            it = graphs.emplace(key, GraphEntry{g, 0}).first;
+        } else {
+            mode = TF_DRY;
+            try { fn(); } catch (...) { mode = TF_EAGER; throw; }
+            mode = TF_EAGER;
+            ++graph_replays;
+        }
+        it->second.used = ++graph_clock;
+        tfb::graph_launch(it->second.graph, stream);
+    }
+    // will factor(c) want the synchronising backward-error check?  (then the step is not captured)
+    bool check_due(double c) {
+        if (refine >= 0) return false;
+        const Checked* like = checked_like(c);
+        return n_factor + 1 <= 4 || !like || n_factor + 1 - like->at >= berr_every;
+    }
+    // refinement sweeps the solves of a factorisation with this c will run (part of the launch string)
+    int sweeps_for(double c) { const Checked* like = checked_like(c); return like ? like->sweeps : -1; }
+    void zero(void* p, size_t nbytes) { if (mode != TF_DRY) tfb::memset0(p, nbytes, stream); }
+    void copy(void* dst, const void* src, size_t nbytes) { if (mode != TF_DRY) tfb::d2d(dst, src, nbytes, stream); }
+
     // timing
     uint64_t timing = 0;     // bit k: time launches of kernel k
     struct Stamp { int kernel; tfb::Event *a, *b; };
@@ -170,6 +226,7 @@ struct tf_solver {
     ~tf_solver() {
         for (auto& st : stamps) { tfb::event_destroy(st.a); tfb::event_destroy(st.b); }
         for (auto* e : event_pool) tfb::event_destroy(e);
+        drop_graphs();
         if (poke_buf) tfb::dev_free(poke_buf);
         if (status) tfb::dev_free(status);
         if (dir_var) tfb::dev_free(dir_var);
@@ -190,6 +247,7 @@ struct tf_solver {
         return tfb::event_create();
     }
     void launch(int kernel, unsigned gx, unsigned gy, unsigned block, const void* args, size_t sz) {
+        if (mode == TF_DRY) return;
         if ((timing >> kernel) & 1ull) {
             Stamp stp{kernel, get_event(), get_event()};
             tfb::launch_timed(model->module, kernel, gx, gy, block, args, sz, stream, stp.a, stp.b);
@@ -340,7 +398,7 @@ struct tf_solver {
     // the copy (schemes.py:144-145, 548-549); without a hook the source slot is read in place.
     const double* stage_input(int src, double* U) {
         if (ndir == 0) return st(src);
-        tfb::d2d(U, st(src), (size_t)vecn() * sizeof(double), stream);
+        copy(U, st(src), (size_t)vecn() * sizeof(double));
         apply_dirichlet(U);
         return U;
     }
@@ -579,6 +637,8 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
     if (opts && opts->device >= 0) tfb::set_device(opts->device);
     mup = std::max(mup, 2);
     s->stream = tfb::stream_create();
+    s->graphs_on = tfb::graphs_supported() && (int64_t)N * nsys <= 50000;
+    if (const char* v = getenv("TRIFLOW_GRAPHS")) s->graphs_on = tfb::graphs_supported() && atoi(v) != 0;
 
     // ---- level plan: chunk levels until a single chunk is left, then the top block.
     // Reduced levels: walks over chunks of m_upper nodes, or -- where the back end has
@@ -778,6 +838,7 @@ int tf_set_dirichlet(tf_solver* s, int32_t n, const int32_t* var, const int64_t*
     TF_API_BEGIN
     require(s, "null solver");
     require(n >= 0, "tf_set_dirichlet: n");
+    s->drop_graphs();                       // the captured launches hold the old buffers
     if (s->dir_var) { tfb::dev_free(s->dir_var); s->dir_var = nullptr; }
     if (s->dir_node) { tfb::dev_free(s->dir_node); s->dir_node = nullptr; }
     s->ndir = 0;
@@ -987,7 +1048,7 @@ void step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns, con
     for (int j = 0; j < ns; ++j) { ks[j] = s->K[j].p; cs[j] = b[j]; }
     s->vec(TF_VEC_SUM, U, Uin, ns, ks, cs);                        // U + sum_i b_i k_i
     if (b_pred && want_err) {
-        tfb::memset0(s->red.p, sizeof(double), s->stream);
+        s->zero(s->red.p, sizeof(double));
         for (int j = 0; j < ns; ++j) cs[j] = b_pred[j];
         s->vec(TF_VEC_MAXABS, nullptr, U, ns, ks, cs);             // ||U - (U + sum b_pred k)||_inf
     }
@@ -1018,10 +1079,15 @@ void diff_norm(tf_solver* s, int32_t slot_a, int32_t slot_b, int32_t ord, double
 }  // namespace
 extern "C" {
 
+namespace {
+std::string bits_of(double v) { uint64_t b; std::memcpy(&b, &v, 8); char buf[20]; snprintf(buf, sizeof buf, "%llx", (unsigned long long)b); return buf; }
+}
 int tf_step_theta(tf_solver* s, int32_t src, int32_t dst, double dt, double theta) {
     TF_API_BEGIN
     require(s, "null solver");
-    step_theta(s, src, dst, dt, theta);
+    const std::string key = "T|" + std::to_string(src) + ">" + std::to_string(dst) + "|" + bits_of(dt) + "|" +
+        bits_of(theta) + "|" + std::to_string(s->ndir) + "|" + std::to_string(s->sweeps_for(theta * dt)) + "|" + std::to_string(s->refine);
+    s->run_graphed(key, !s->check_due(theta * dt), [&] { step_theta(s, src, dst, dt, theta); });
     TF_API_END
 }
 
@@ -1030,7 +1096,14 @@ int tf_step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns,
                 const double* b_pred, int32_t hook_after, double* err_out) {
     TF_API_BEGIN
     require(s && alpha && gamma && b, "null argument");
-    step_row(s, src, dst, dt, ns, alpha, gamma, b, b_pred, hook_after != 0, err_out != nullptr);
+    require(ns >= 1 && ns <= 6, "tf_step_row: 1 <= s <= 6");
+    std::string key = "R|" + std::to_string(src) + ">" + std::to_string(dst) + "|" + bits_of(dt) + "|" +
+        std::to_string(ns) + "|" + std::to_string(hook_after) + "|" + std::to_string(s->ndir) + "|" +
+        std::to_string(s->sweeps_for(gamma[0] * dt)) + "|" + std::to_string(s->refine) + "|" + (b_pred && err_out ? "e" : "-");
+    for (int i = 0; i < ns * ns; ++i) key += bits_of(alpha[i]) + bits_of(gamma[i]);
+    for (int i = 0; i < ns; ++i) key += bits_of(b[i]) + (b_pred ? bits_of(b_pred[i]) : std::string("-"));
+    s->run_graphed(key, !s->check_due(gamma[0] * dt), [&] {
+        step_row(s, src, dst, dt, ns, alpha, gamma, b, b_pred, hook_after != 0, err_out != nullptr); });
     if (err_out) {
         *err_out = 0.0;
         if (b_pred) {
@@ -1166,7 +1239,7 @@ int tf_debug_stamps(tf_solver* s, uint64_t* out, int32_t max_levels) {
     TF_API_BEGIN
     require(s && out, "null argument");
     const size_t need = 64 * std::max<size_t>(s->levels.size(), 1);
-    if (s->stamp_buf.n < need) { s->stamp_buf.alloc(need, s->bytes); return 0; }
+    if (s->stamp_buf.n < need) { s->drop_graphs(); s->stamp_buf.alloc(need, s->bytes); return 0; }
     const size_t n = 64 * std::min<size_t>(s->levels.size(), (size_t)std::max(max_levels, 0));
     tfb::d2h(out, s->stamp_buf.p, n * sizeof(uint64_t), s->stream);
     TF_API_END
