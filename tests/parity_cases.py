@@ -614,6 +614,51 @@ def check_unstable_factorisation_is_loud(backend):
     assert refined and omega < 1e-10
 
 
+def check_row_monitor(backend):
+    """Every Rosenbrock step measures the backward error of its factorisation inside the J @ v
+    pass of stage 1 (quotients are only formed above 1e-12).  (i) A healthy factorisation reads 0,
+    like the explicit check of the same solve reads rounding level.  (ii) A factorisation that
+    loses accuracy while no explicit check runs -- a dispersive model on 4-node chunks, checks
+    switched off -- is reported by the next synchronising call instead of passing silently."""
+    from triflow_amd.ensemble import Ensemble
+    name, fd, pars, dt, _ = corpus.config_inputs(3, 3000)
+    m = device_model(name, backend)
+    fields = {k: v[None, :] for k, v in fd.items() if k != "x"}
+    ens = Ensemble(m, fd["x"], fields, pars, True, scheme="ROS2", nstate=2)
+    ens.step(dt)
+    mon = ens.solver.monitor_error()
+    chk, _ = ens.solver.backward_error()
+    assert mon == 0.0 and 0 < chk < 1e-12, (mon, chk)
+    ens.sync()                                                  # resets the monitor
+    assert ens.solver.monitor_error() == 0.0
+    ens.close()
+    # (ii) KdV on 4-node chunks at c / dx^3 >> 1 (the plan of check_unstable_factorisation_is_loud),
+    # explicit checks off (refine = -2: the monitor only): the steps run unchecked, the next
+    # synchronising call raises
+    N = 203
+    x = np.linspace(0, N * 5e-3, N, endpoint=False)
+    mk = device_model("kdv", backend)
+    U = (1.0 + 0.3 * np.cos(2 * np.pi * x / x[-1]))[None, :]
+    ens = Ensemble(mk, x, dict(U=U), dict(periodic=True), True, scheme="ROS2", nstate=2, m1=4, m_upper=2,
+                   refine=-2)
+    for _ in range(3):
+        ens.step(0.1)
+    assert ens.solver.monitor_error() > 1e-6
+    raised = False
+    try:
+        ens.sync()
+    except RuntimeError as ex:
+        raised = "lost accuracy" in str(ex)
+    assert raised
+    # the default plan of the same problem passes the monitor
+    ens = Ensemble(mk, x, dict(U=U), dict(periodic=True), True, scheme="ROS2", nstate=2, refine=-2)
+    for _ in range(3):
+        ens.step(0.1)
+    worst = ens.solver.monitor_error()
+    ens.sync()
+    assert worst < 1e-6, worst
+
+
 def check_ensemble_equals_single_members(backend, N=3000, nsys=3, steps=3, exact=True, **opts):
     """nsys members stepped together in one solver (per-member scalar parameters and
     initial conditions) give, member by member, the bits of nsys separate single-member

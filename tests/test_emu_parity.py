@@ -100,6 +100,10 @@ def test_container_on_device_fields(backend, tmp_path):
     pc.check_container_on_device_fields(backend, tmp_path)
 
 
+def test_row_monitor(backend):
+    pc.check_row_monitor(backend)
+
+
 def test_unstable_factorisation_is_loud(backend):
     pc.check_unstable_factorisation_is_loud(backend)
 

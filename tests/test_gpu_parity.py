@@ -381,6 +381,10 @@ def test_model_load_reuses_code_object(tmp_path):
     pc.check_model_load_reuses_code_object(HIP, tmp_path)
 
 
+def test_row_monitor():
+    pc.check_row_monitor(HIP)
+
+
 def test_unstable_factorisation_is_loud():
     pc.check_unstable_factorisation_is_loud(HIP)
 

@@ -79,6 +79,7 @@ SIGNATURES = {
     "tf_step_doubling": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double,
                                    C.c_int32, C.c_int32, C.POINTER(Scheme), C.c_int32, c_double_p]),
     "tf_backward_error": (C.c_int, [C.c_void_p, c_double_p, c_int32_p]),
+    "tf_monitor_error": (C.c_int, [C.c_void_p, c_double_p]),
     "tf_sync": (C.c_int, [C.c_void_p]),
     "tf_timing_enable": (C.c_int, [C.c_void_p, C.c_int64]),
     "tf_timing_reset": (C.c_int, [C.c_void_p]),
@@ -374,6 +375,13 @@ class DeviceSolver:
         om, flag = C.c_double(0.0), C.c_int32(0)
         self.lib.call("tf_backward_error", self.handle, C.byref(om), C.byref(flag))
         return om.value, bool(flag.value)
+
+    def monitor_error(self):
+        """Worst backward error seen by the in-pass monitor of the Rosenbrock steps since the last
+        synchronising call."""
+        w = C.c_double(0.0)
+        self.lib.call("tf_monitor_error", self.handle, C.byref(w))
+        return w.value
 
     def sync(self):
         self.lib.call("tf_sync", self.handle)

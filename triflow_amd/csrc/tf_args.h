@@ -72,6 +72,12 @@ struct TfSpmvArgs {                // y = scale * J @ v  (clamped/wrapped column
     double vc[TF_MAX_TERMS];
     const double* addF;
     double cF, cA;
+    // Monitor of the previous solve (Rosenbrock stage 1: v = g * k0 with k0 the solution of
+    // (I - cJ) k0 = mon_rhs): its componentwise backward error  |b - x + cJx| / (|x| + |cJ||x| + |b|)
+    // falls out of this pass over J; the maximum goes to *mon_red (atomic max of the bit pattern).
+    const double* mon_rhs;          // NULL: off
+    double mon_c, mon_inv_g;
+    double* mon_red;
 };
 
 struct TfNormArgs {               // per-variable, per-system norm of (a - b): partial sums
@@ -211,11 +217,12 @@ enum TfKernel {
     TFK_L1_FACTOR, TFK_L1_SOLVE, TFK_L1_ASM_MAT, TFK_L1_ASM_RHS, TFK_L1_BACKSUB,
     TFK_BT_LU, TFK_BT_SPIKE, TFK_BT_RHS, TFK_BT_ASM_MAT, TFK_BT_ASM_RHS, TFK_BT_BACKSUB,
     TFK_TOP_FACTOR, TFK_TOP_SOLVE, TFK_BERR, TFK_DIFFNORM, TFK_L1_FACTOR_RHS, TFK_SWEEP_F_STAGE,
-    TFK_CR_FACTOR, TFK_CR_FWD, TFK_CR_BWD, TFK_POKE, TFK_SWEEP_FJ_THETA, TFK_SWEEP_FJ_BDF2, TFK_COUNT
+    TFK_CR_FACTOR, TFK_CR_FWD, TFK_CR_BWD, TFK_POKE, TFK_SWEEP_FJ_THETA, TFK_SWEEP_FJ_BDF2, TFK_SPMV_MON, TFK_COUNT
 };
 #define TF_KERNEL_NAMES { \
     "tfk_sweep_f", "tfk_sweep_fj", "tfk_spmv", "tfk_vec", "tfk_vec_maxabs", "tfk_perm", "tfk_dirichlet", \
     "tfk_l1_factor", "tfk_l1_solve", "tfk_l1_asm_mat", "tfk_l1_asm_rhs", "tfk_l1_backsub", \
     "tfk_bt_lu", "tfk_bt_spike", "tfk_bt_rhs", "tfk_bt_asm_mat", "tfk_bt_asm_rhs", "tfk_bt_backsub", \
     "tfk_top_factor", "tfk_top_solve", "tfk_berr", "tfk_diffnorm", "tfk_l1_factor_rhs", "tfk_sweep_f_stage", \
-    "tfk_cr_factor", "tfk_cr_fwd", "tfk_cr_bwd", "tfk_poke", "tfk_sweep_fj_theta", "tfk_sweep_fj_bdf2" }
+    "tfk_cr_factor", "tfk_cr_fwd", "tfk_cr_bwd", "tfk_poke", "tfk_sweep_fj_theta", "tfk_sweep_fj_bdf2", \
+    "tfk_spmv_mon" }

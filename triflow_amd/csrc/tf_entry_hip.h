@@ -38,7 +38,21 @@ __global__ void TF_SWEEP_ATTR __launch_bounds__(TF_SWEEP_BLOCK) tfk_sweep_fj_bdf
     tfk_sweep_body<true, false, false, true>(a, TF_GID, blockIdx.y);
 }
 __global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_spmv(TfSpmvArgs a) {
-    tfk_spmv_body(a, TF_GID, blockIdx.y);
+    tfk_spmv_body<false>(a, TF_GID, blockIdx.y);
+}
+// the same product plus the backward-error monitor of the previous solve (TfSpmvArgs::mon_rhs)
+__global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_spmv_mon(TfSpmvArgs a) {
+    const double m = tfk_spmv_body<true>(a, TF_GID, blockIdx.y);
+    {
+        unsigned long long bits = (unsigned long long)__double_as_longlong(m);
+        if (m != m) bits = 0x7ff8000000000000ull;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(bits, off, 64);
+            bits = o > bits ? o : bits;
+        }
+        if ((threadIdx.x & 63) == 0 && bits != 0) atomicMax((unsigned long long*)a.mon_red, bits);
+    }
 }
 
 // ---- plane algebra: grid-stride, 16 B per lane where the planes allow ------

@@ -211,13 +211,17 @@ TF_DEVICE void tfk_sweep_body(const TfSweepArgs& a, int pg, int seg) {
 // 2. y = scale * (J @ v)      (CSC product of schemes.py:157, 553; the column
 //    of a stored value is the clamped / wrapped neighbour, compilers.py:303-328)
 // ===========================================================================
-TF_DEVICE void tfk_spmv_body(const TfSpmvArgs& a, int pg, int seg) {
+// MON: also the monitor of TfSpmvArgs::mon_rhs; returns this thread's share of it (else 0).
+// A kernel of its own (tfk_spmv_mon): the magnitudes cost registers the plain product keeps free.
+template <bool MON = false>
+TF_DEVICE double tfk_spmv_body(const TfSpmvArgs& a, int pg, int seg) {
     const TfLayout& L = a.L;
-    if (pg >= L.Ptot) return;
+    if (pg >= L.Ptot) return 0.0;
     const int e = pg / L.P, p = pg - e * L.P;
     const int len = tf_len(L, p);
     const int i0 = seg * TF_SEG;
-    if (i0 >= len) return;
+    if (i0 >= len) return 0.0;
+    double worst = 0.0;
     auto ld = [&](int v, int ii) -> double {
         const int64_t s = (ii >= 0 && ii < len) ? tf_idx(L, pg, ii) : tf_nbr(L, e, p, len, 0, ii);
         if (a.nterms == 0) return a.v[(int64_t)v * L.plane + s];
@@ -243,22 +247,41 @@ TF_DEVICE void tfk_spmv_body(const TfSpmvArgs& a, int pg, int seg) {
                 w[v][TF_W - 1] = ld(v, i + TF_MP);
             }
             const int64_t s = tf_idx(L, pg, i);
-            double acc[TF_NVAR];
+            double acc[TF_NVAR], mag[TF_NVAR];
 #pragma unroll
-            for (int v = 0; v < TF_NVAR; ++v) acc[v] = 0.0;
+            for (int v = 0; v < TF_NVAR; ++v) { acc[v] = 0.0; mag[v] = 0.0; }
+            constexpr bool mon = MON;
 #pragma unroll
             for (int k = 0; k < TF_NNZ; ++k) {       // pattern order = ascending column
                 double jv = a.scale * (TF_JU(k) ? ju.v[k] : a.Jv[(int64_t)k * L.plane + s]);
                 double wv = w[tf_pat_var[k]][tf_pat_off[k] + TF_MP];
                 if (a.absval) { jv = tf_abs(jv); wv = tf_abs(wv); }
                 acc[tf_pat_eq[k]] = acc[tf_pat_eq[k]] + jv * wv;
+                if (mon) mag[tf_pat_eq[k]] = tf_fma(tf_abs(jv), tf_abs(wv), mag[tf_pat_eq[k]]);
             }
 #pragma unroll
             for (int v = 0; v < TF_NVAR; ++v)
                 a.y[(int64_t)v * L.plane + s] = a.addF
                     ? a.cF * a.addF[(int64_t)v * L.plane + s] + a.cA * acc[v] : acc[v];
+            if (mon) {
+                // acc = J (g x), mag = |J| |g x|: the residual of (I - cJ) x = b at this node.  The
+                // quotient is only formed where it is above the refinement trigger (rare).
+                const double ag = tf_abs(a.mon_inv_g), ac = tf_abs(a.mon_c);
+#pragma unroll
+                for (int v = 0; v < TF_NVAR; ++v) {
+                    const double b = a.mon_rhs[(int64_t)v * L.plane + s];
+                    const double xv = w[v][TF_MP] * a.mon_inv_g;
+                    const double num = tf_abs((b - xv) + a.mon_c * (acc[v] * a.mon_inv_g));
+                    const double den = tf_abs(xv) + ac * (mag[v] * ag) + tf_abs(b);
+                    if (num > 1e-12 * den || num != num) {
+                        const double q = num / den;
+                        worst = (q > worst || q != q) ? q : worst;
+                    }
+                }
+            }
         }
     }
+    return worst;
 }
 
 // componentwise (Oettli-Prager) backward error of (I - cJ) x = b, one pass over J:

@@ -128,7 +128,7 @@ struct tf_solver {
     double factor_c = 0.0;
     bool have_factor = false, have_jac = false;
     bool fact_checked = false, fact_needs_refine = false;   // refine == -1 (auto)
-    double last_omega = 0.0, refine_trigger = 1e-11;
+    double last_omega = 0.0, refine_trigger = 1e-11, monitor_omega = 0.0;
     // the backward-error check is a monitor: every factorisation while the matrix is new
     // (first 4, or c changed by > 10 %), then every berr_every-th one
     int berr_every = 8;
@@ -206,7 +206,7 @@ struct tf_solver {
     }
     // will factor(c) want the synchronising backward-error check?  (then the step is not captured)
     bool check_due(double c) {
-        if (refine >= 0) return false;
+        if (refine != -1) return false;
         const Checked* like = checked_like(c);
         return n_factor + 1 <= 4 || !like || n_factor + 1 - like->at >= berr_every;
     }
@@ -334,13 +334,13 @@ struct tf_solver {
     }
 
     void sweep(const double* fields, bool with_j, int nterms = 0, const double* const* kx = nullptr,
-               const double* kc = nullptr, double fscale = 1.0) {
+               const double* kc = nullptr, double fscale = 1.0, double* Fout = nullptr) {
         TfSweepArgs a;
         std::memset(&a, 0, sizeof(a));
         a.nterms = nterms; a.fscale = fscale;
         for (int t = 0; t < nterms; ++t) { a.kx[t] = kx[t]; a.kc[t] = kc[t]; }
         a.L = L1; a.fields = fields; a.helpers = helpers.p; a.parvec = parvec.p; a.parsca = parsca.p;
-        a.dx = dx.p; a.xcoord = xcoord.p; a.F = F.p; a.Jv = Jv.p; a.with_j = with_j ? 1 : 0;
+        a.dx = dx.p; a.xcoord = xcoord.p; a.F = Fout ? Fout : F.p; a.Jv = Jv.p; a.with_j = with_j ? 1 : 0;
         unsigned gx = sweep_gx(), gy = cdiv(L1.M, spec.seg);
         if (nterms > 0 && with_j) throw std::logic_error("stage sweep evaluates F only");
         launch(with_j ? TFK_SWEEP_FJ : (nterms > 0 ? TFK_SWEEP_F_STAGE : TFK_SWEEP_F), gx, gy,
@@ -381,17 +381,26 @@ struct tf_solver {
     }
 
     // y = cF*F + cA*(J @ sum_t vc_t vx_t): stage right-hand side of a ROW scheme in one pass
+    // monitor_rhs != NULL (first stage product of a Rosenbrock step, one term g*k0): the same pass
+    // measures the backward error of the solve that produced k0 from monitor_rhs (red[4])
     void spmv_stage(int nterms, const double* const* vx, const double* vc, const double* Fp,
-                    double cF, double cA, double* y) {
+                    double cF, double cA, double* y, const double* monitor_rhs = nullptr) {
         TfSpmvArgs a;
         std::memset(&a, 0, sizeof(a));
+        // (every monitor_every-th factorisation: the magnitudes make this pass 60 % slower)
+        const bool mon = monitor_rhs && nterms == 1 && vc[0] != 0.0 && refine < 0 &&
+                         (refine == -2 || n_factor % monitor_every == monitor_every / 2);
+        if (mon) {
+            a.mon_rhs = monitor_rhs; a.mon_c = factor_c; a.mon_inv_g = 1.0 / vc[0]; a.mon_red = red.p + 4;
+            monitored = true;
+        }
         a.L = L1; a.Jv = Jv.p; a.v = nullptr; a.y = y; a.scale = 1.0;
         a.parsca = parsca.p; a.dx = dx.p;
         a.nterms = nterms;
         for (int t = 0; t < nterms; ++t) { a.vx[t] = vx[t]; a.vc[t] = vc[t]; }
         a.addF = Fp; a.cF = cF; a.cA = cA;
         unsigned gx = sweep_gx(), gy = cdiv(L1.M, spec.seg);
-        launch(TFK_SPMV, gx, gy, spec.sweep_block, &a, sizeof(a));
+        launch(mon ? TFK_SPMV_MON : TFK_SPMV, gx, gy, spec.sweep_block, &a, sizeof(a));
     }
 
     // State a step starts from: the reference copies the fields and applies the hook to
@@ -463,9 +472,9 @@ struct tf_solver {
         have_factor = true;
         ++n_factor;
         const Checked* like = checked_like(c);
-        check_now = n_factor <= 4 || !like || n_factor - like->at >= berr_every;
+        check_now = refine == -1 && (n_factor <= 4 || !like || n_factor - like->at >= berr_every);
         if (check_now) { fact_checked = false; fact_needs_refine = false; sweeps_needed = 0; }
-        else { sweeps_needed = like->sweeps; fact_needs_refine = sweeps_needed > 0; }
+        else if (like) { sweeps_needed = like->sweeps; fact_needs_refine = sweeps_needed > 0; }
         // (between checks the verdict of the last checked factorisation with such a c stands)
         if (rhs1 == nullptr) return;
         if (!fused) { solve(rhs1, x1); return; }
@@ -536,7 +545,7 @@ struct tf_solver {
     void polish(const double* rhs1, double* x1) {
         if (refine > 0) {
             for (int it = 0; it < refine; ++it) refine_sweep(rhs1, x1);
-        } else if (refine < 0) {
+        } else if (refine == -1) {
             if (!fact_checked) {
                 last_omega = backward_error(rhs1, x1);
                 fact_checked = true;
@@ -566,9 +575,28 @@ struct tf_solver {
         }
     }
 
+    // Between two explicit (synchronising) checks a Rosenbrock step measures the backward error
+    // of its factorisation inside its first J @ v pass (tfk_spmv_mon: no launch of its own, no
+    // synchronisation); with refine = -2 every step does.  The worst value since the last look is
+    // read here, at the synchronising calls.
+    bool monitored = false;
+    int monitor_every = 8;     // ... halfway between two explicit checks (berr_every)
     void check_status() {
         int flag = 0;
         tfb::d2h(&flag, status, sizeof(int), stream);
+        if (monitored) {
+            double worst = 0.0;
+            tfb::d2h(&worst, red.p + 4, sizeof(double), stream);
+            tfb::memset0(red.p + 4, sizeof(double), stream);
+            monitored = false;
+            if (worst > refine_trigger || worst != worst) {
+                // some factorisation since the last check lost accuracy that the checked ones had
+                // not: forget the verdicts, the next factorisation is checked (and refined)
+                checked.clear();
+                monitor_omega = worst;
+                if (!(worst <= 1e-6)) { last_omega = worst; unstable = true; }
+            }
+        }
         if (flag != 0) {
             tfb::memset0(status, sizeof(int), stream);
             throw std::runtime_error("banded solver: singular or non-finite pivot block");
@@ -632,7 +660,9 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
     int m1 = opts && opts->m1 > 0 ? opts->m1 : 0;             // 0: chosen below from the problem size
     int mup = opts && opts->m_upper > 0 ? opts->m_upper : 6;
     s->nstate = opts && opts->nstate > 0 ? opts->nstate : 3;
-    s->refine = opts ? opts->refine : -1;      // 0 = never, n > 0 = fixed sweeps, -1 = auto
+    // 0 = never, n > 0 = fixed sweeps, -1 = auto (explicit checks + the in-pass monitor of the
+    // Rosenbrock steps), -2 = the monitor only (no synchronising check at all)
+    s->refine = opts ? opts->refine : -1;
     if (opts && opts->berr_every > 0) s->berr_every = opts->berr_every;
     if (opts && opts->device >= 0) tfb::set_device(opts->device);
     mup = std::max(mup, 2);
@@ -1035,12 +1065,14 @@ void step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns, con
     double cs[TF_MAX_TERMS];
     for (int i = 0; i < ns; ++i) {
         if (i > 0) {
-            // F(U + sum_j alpha_ij k_j): the stage state is formed inside the sweep
+            // F(U + sum_j alpha_ij k_j): the stage state is formed inside the sweep.  It goes to a
+            // buffer of its own: F keeps dt*F(U), the right-hand side of stage 0, for the monitor
             for (int j = 0; j < i; ++j) { ks[j] = s->K[j].p; cs[j] = alpha[i * ns + j]; }
-            s->sweep(Uin, false, i, ks, cs);
-            // dt*F + dt*(J @ sum_j gamma_ij k_j) in one pass over J
+            s->sweep(Uin, false, i, ks, cs, 1.0, s->Wstage.p);
+            // dt*F + dt*(J @ sum_j gamma_ij k_j) in one pass over J; for i == 1 the pass also
+            // measures the backward error of the stage-0 solve (k0 from dt*F(U))
             for (int j = 0; j < i; ++j) cs[j] = gamma[i * ns + j];
-            s->spmv_stage(i, ks, cs, s->F.p, dt, dt, s->Wrhs.p);
+            s->spmv_stage(i, ks, cs, s->Wstage.p, dt, dt, s->Wrhs.p, i == 1 ? s->F.p : nullptr);
         }
         if (i == 0) s->factor(gamma[0] * dt, s->F.p, s->K[0].p);      // factorise + first stage
         else s->solve(s->Wrhs.p, s->K[i].p);
@@ -1099,7 +1131,8 @@ int tf_step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns,
     require(ns >= 1 && ns <= 6, "tf_step_row: 1 <= s <= 6");
     std::string key = "R|" + std::to_string(src) + ">" + std::to_string(dst) + "|" + bits_of(dt) + "|" +
         std::to_string(ns) + "|" + std::to_string(hook_after) + "|" + std::to_string(s->ndir) + "|" +
-        std::to_string(s->sweeps_for(gamma[0] * dt)) + "|" + std::to_string(s->refine) + "|" + (b_pred && err_out ? "e" : "-");
+        std::to_string(s->sweeps_for(gamma[0] * dt)) + "|" + std::to_string(s->refine) + "|" + (b_pred && err_out ? "e" : "-") +
+        ((s->n_factor + 1) % s->monitor_every == s->monitor_every / 2 ? "m" : "-");
     for (int i = 0; i < ns * ns; ++i) key += bits_of(alpha[i]) + bits_of(gamma[i]);
     for (int i = 0; i < ns; ++i) key += bits_of(b[i]) + (b_pred ? bits_of(b_pred[i]) : std::string("-"));
     s->run_graphed(key, !s->check_due(gamma[0] * dt), [&] {
@@ -1242,6 +1275,16 @@ int tf_debug_stamps(tf_solver* s, uint64_t* out, int32_t max_levels) {
     if (s->stamp_buf.n < need) { s->drop_graphs(); s->stamp_buf.alloc(need, s->bytes); return 0; }
     const size_t n = 64 * std::min<size_t>(s->levels.size(), (size_t)std::max(max_levels, 0));
     tfb::d2h(out, s->stamp_buf.p, n * sizeof(uint64_t), s->stream);
+    TF_API_END
+}
+
+// Worst backward error the in-pass monitor of the Rosenbrock steps has seen since the last
+// synchronising call (tf_sync / downloads reset it), without raising.
+int tf_monitor_error(tf_solver* s, double* worst) {
+    TF_API_BEGIN
+    require(s && worst, "null argument");
+    *worst = 0.0;
+    if (s->monitored) tfb::d2h(worst, s->red.p + 4, sizeof(double), s->stream);
     TF_API_END
 }
 
