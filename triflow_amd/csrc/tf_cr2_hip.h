@@ -1,17 +1,18 @@
-// Cyclic-reduction factorisation of a reduced-level chunk, second version (3 <= b <= 8).
+// Cyclic-reduction factorisation of a reduced-level chunk with a WAVEFRONT per node (3 <= b <= 8).
 //
-// Same algorithm, task lists, stored quantities (a.crf, a.zt) and outputs as
-// tfk_cr_factor_coop (tf_coop_hip.h) -- the solve kernels tfk_cr_fwd / tfk_cr_bwd read what
-// either writes -- but built around the latency of one round, which is what these levels
-// cost (one wavefront per chunk, 4 rounds of dependent block inversions):
-//   * Gauss-Jordan on the augmented row [D | I | L | U | y] of the node that goes: the
-//     lane ends with its rows of D^-1, E = D^-1 L, F = D^-1 U and z = D^-1 y, no product
-//     phase after the inversion;
-//   * the pivot lane of a step is found with three DPP max steps inside the 8-lane group
-//     (key = float magnitude with the lane number in its low bits), not through LDS, and
-//     only that lane publishes its row: one LDS round trip of 4b+1 doubles per pivot;
-//   * the chain lives in LDS as records per (position, block row) with a stride chosen
-//     against bank conflicts, ~20 KB per chunk instead of 36: two wavefronts per SIMD.
+// Same algorithm, task lists, stored quantities (a.crf, a.zt) and outputs as tfk_cr_factor_coop
+// (tf_coop_hip.h, the round-1 version: 8 lanes per node, kept as -DTF_CR_V2=0 for A/B runs) -- the
+// solve kernels tfk_cr_fwd / tfk_cr_bwd read what either writes -- but built around what these
+// levels cost: the latency of a round of dependent block inversions.  With 8 lanes per node every
+// pivot step is ~160 instructions of ONE wavefront (measured: 1300 cycles per pivot, 11 000 per
+// round, also with a DPP pivot search and a conflict-free LDS image: profiles/README.md).  Here:
+//   * Gauss-Jordan on the augmented row [L | D | U | y | I] of the node that goes: the lanes end
+//     with D^-1, E = D^-1 L, F = D^-1 U and z = D^-1 y, no product phase after the inversion;
+//   * the pivot row of a step is found with three DPP max steps inside an 8-lane group (key =
+//     float magnitude with the lane number in its low bits) and reaches the other rows through
+//     ds_bpermute (lane crossbar: no LDS memory, no barrier);
+//   * the chain lives in LDS as records per (position, block row) with a stride chosen against
+//     bank conflicts, 16 KB per chunk instead of 36.
 // HIP only.
 #pragma once
 
@@ -20,7 +21,7 @@
 // the ones for which the access patterns of all rounds (own row of the nodes that go, rows of
 // the updated neighbours, broadcast reads of E / F / z) hit distinct banks: average conflict
 // degree 1.01 - 1.04, worst 2 (searched over RS <= RW + 3, PS <= b*RS + 15; the natural
-// [pos][4][b][b] image of the first version is 4- to 8-way).
+// [pos][4][b][b] image of the round-1 version is 4- to 8-way).
 template <int BB> struct TfCr2Stride;
 template <> struct TfCr2Stride<3> { static constexpr int RS = 11, PS = 38; };
 template <> struct TfCr2Stride<4> { static constexpr int RS = 13, PS = 54; };
@@ -30,11 +31,10 @@ template <> struct TfCr2Stride<7> { static constexpr int RS = 23, PS = 166; };
 template <> struct TfCr2Stride<8> { static constexpr int RS = 25, PS = 202; };
 
 template <int BB> struct TfCr2 {
-    static constexpr int G = 8, NGRP = 8, MAXLEN = TF_CR_MAXLEN, NPOS = MAXLEN + 1;
+    static constexpr int MAXLEN = TF_CR_MAXLEN, NPOS = MAXLEN + 1;
     static constexpr int RW = 3 * BB + 1;                 // L | D | U | y of one block row
     static constexpr int RS = TfCr2Stride<BB>::RS;        // row stride
     static constexpr int PS = TfCr2Stride<BB>::PS;        // position stride
-    static constexpr int XW = 4 * BB + 1;                 // published pivot row
     static constexpr int oL = 0, oD = BB, oU = 2 * BB, oY = 3 * BB;
     static_assert(RS >= RW && PS >= BB * RS, "strides");
 };
@@ -49,311 +49,16 @@ __device__ __forceinline__ unsigned tf_group8_max(unsigned v) {
     return o > v ? o : v;
 }
 
-// Gauss-Jordan with partial pivoting on [S | A] shared by the 8 lanes of a group: lane g
-// enters with row g (S: the b x b block, A: NA augmented columns) and leaves with row `myk`
-// (returned) of [I | S^-1 A].  Rows are never moved; the unused lane with the largest
-// |S[.][k]| (as float; the lowest lane on ties) serves pivot k and publishes its row
-// through `xch` ([2][XW] doubles of this group, double buffered).
-template <int BB, int NA, int XW>
-__device__ __forceinline__ int tf_gj_aug(double (&S)[BB], double (&A)[NA], bool on, int g,
-                                         double* xch, bool& ok) {
-    static_assert(BB + NA <= XW, "exchange row too short");
-    int myk = -1;
-#pragma unroll
-    for (int kk = 0; kk < BB; ++kk) {
-        unsigned key = 0;
-        if (on && myk < 0) {
-            const float mag = (float)tf_abs(S[kk]);
-            unsigned bits = __float_as_uint(mag);
-            if (bits == 0 && S[kk] != 0.0) bits = 8;               // underflow is not a zero pivot
-            if (mag != mag) bits = 0x7f800000u;                    // NaN: taken, reported through ok
-            key = (bits & ~7u) | (unsigned)(7 - g);
-        }
-        const unsigned best = tf_group8_max(key);
-        const bool mine = on && myk < 0 && key == best;
-        double* buf = xch + (kk & 1) * XW;
-        if (mine) {
-#pragma unroll
-            for (int c = 0; c < BB; ++c) buf[c] = S[c];
-#pragma unroll
-            for (int c = 0; c < NA; ++c) buf[BB + c] = A[c];
-        }
-        __syncthreads();
-        const double pv = buf[kk];
-        if (on) ok = ok && (pv != 0.0) && tf_finite(pv);
-        const double rp = 1.0 / pv;
-        if (mine) myk = kk;
-        const double f2 = mine ? 0.0 : -S[kk] * rp;
-#pragma unroll
-        for (int c = 0; c < BB; ++c) S[c] = tf_fma(f2, buf[c], S[c]);
-#pragma unroll
-        for (int c = 0; c < NA; ++c) A[c] = tf_fma(f2, buf[BB + c], A[c]);
-        if (mine) {
-#pragma unroll
-            for (int c = 0; c < BB; ++c) S[c] *= rp;
-#pragma unroll
-            for (int c = 0; c < NA; ++c) A[c] *= rp;
-        }
-    }
-    return myk;
-}
-
-template <int BB>
-__device__ __forceinline__ void tfk_cr_factor_v2(const TfLevelArgs& a) {
-    typedef TfCr2<BB> C;
-    constexpr int G = C::G, NGRP = C::NGRP, NPOS = C::NPOS, B2 = BB * BB, REC = 4 * B2;
-    constexpr int RS = C::RS, PS = C::PS, XW = C::XW, NA = 3 * BB + 1;
-    constexpr int oL = C::oL, oD = C::oD, oU = C::oU, oY = C::oY;
-    const TfLayout& L = a.L;
-    const TfCrChunk<BB> ch(L);
-    const int tid = threadIdx.x, grp = tid / G, g = tid % G;
-    const bool row_on = g < BB;
-    const int gq = row_on ? g : 0;
-    const int mI = ch.mI, pe = ch.pe, len = ch.len;
-    const bool with_rhs = a.cr_rhs != 0;
-
-    __shared__ double sRow[NPOS * PS];
-    __shared__ double sX[NGRP * 2 * XW];
-    auto row = [&](int pos, int r) { return sRow + pos * PS + r * RS; };
-
-    TF_STAMP_REAL(a, 30);
-    TF_STAMP(a, 0);
-    // ---- load: records [node][L, D, U, second part of D][b][b] of a chunk are contiguous
-    {
-        const double* src = a.Ablk + (ch.nbase + ch.start) * REC;
-        const int n3 = len * 3 * B2;
-#pragma unroll 4
-        for (int i = tid; i < n3; i += 64) {
-            const int nd = i / (3 * B2), rem = i - nd * 3 * B2;
-            const int blk = rem / B2, rc = rem - blk * B2, r = rc / BB, c = rc - r * BB;
-            double v = src[nd * REC + blk * B2 + rc];
-            if (blk == 1) v += src[nd * REC + 3 * B2 + rc];        // D = both parts
-            row(nd + 1, r)[blk * BB + c] = v;
-        }
-        // position 0: the separator above; only its U block couples into this chunk
-        const double* prev = a.Ablk + (ch.nbase + ch.gprev) * REC + 2 * B2;
-        for (int i = tid; i < 3 * B2; i += 64) {
-            const int blk = i / B2, rc = i - blk * B2, r = rc / BB, c = rc - r * BB;
-            row(0, r)[blk * BB + c] = (blk == 2 && ch.has_prev) ? prev[rc] : 0.0;
-        }
-        const double* ys = a.rhs + (ch.nbase + ch.start) * 2 * BB;
-        for (int i = tid; i < (len + 1) * BB; i += 64) {
-            const int pos = i / BB, r = i - pos * BB;
-            row(pos, r)[oY] = (with_rhs && pos > 0) ? ys[(pos - 1) * 2 * BB + r] + ys[(pos - 1) * 2 * BB + BB + r] : 0.0;
-        }
-    }
-    __syncthreads();
-    if (!L.periodic) {                               // no neighbour beyond the ends of a system
-        if (ch.start == 0 && tid < B2) row(1, tid / BB)[oL + tid % BB] = 0.0;
-        if (ch.start + len == L.N && tid < B2) row(pe, tid / BB)[oU + tid % BB] = 0.0;
-        __syncthreads();
-    }
-
-    bool ok = true;
-    double* xch = sX + grp * 2 * XW;
-    TF_STAMP(a, 1);
-    int stamp_i = 2;
-    for (int s = 1; s <= mI; s <<= 1) {
-        // ---- phase A: the nodes k = s * (2 grp + 1) go; lane g takes row g of [D | I L U y]
-        const int nA = (mI / s + 1) / 2;             // <= 8: one per group
-        {
-            const bool on = grp < nA && row_on;
-            const int k = grp < nA ? s * (2 * grp + 1) : 1;
-            const double* rk = row(k, gq);
-            double S[BB], A[NA];
-#pragma unroll
-            for (int c = 0; c < BB; ++c) {
-                S[c] = rk[oD + c];
-                A[c] = c == g ? 1.0 : 0.0;
-                A[BB + c] = rk[oL + c];
-                A[2 * BB + c] = rk[oU + c];
-            }
-            A[3 * BB] = rk[oY];
-            const int myk = tf_gj_aug<BB, NA, XW>(S, A, on, g, xch, ok);
-            // A = rows myk of D^-1 | E | F | z
-            if (on) {
-                double* rec = a.crf + (ch.nbase + ch.node(k)) * 5 * B2 + myk * BB;
-                double* dst = row(k, myk);
-#pragma unroll
-                for (int c = 0; c < BB; ++c) {
-                    rec[0 * B2 + c] = A[c];
-                    rec[1 * B2 + c] = A[BB + c];
-                    rec[2 * B2 + c] = A[2 * BB + c];
-                    dst[oL + c] = A[BB + c];
-                    dst[oU + c] = A[2 * BB + c];
-                }
-                dst[oY] = A[3 * BB];
-                if (with_rhs) a.zt[(ch.nbase + ch.node(k)) * BB + myk] = A[3 * BB];
-            }
-        }
-        __syncthreads();
-        TF_STAMP(a, stamp_i); ++stamp_i;
-        // ---- phase B: the neighbours take the update, one task per group.  Interior
-        //      a = 2s(t+1): its L side lost kL = a-s, its U side loses kR = a+s (if there).
-        //      Last task: the L side of the own separator (pe) and the U side of position 0.
-        const int nB = mI / (2 * s);                 // <= 7
-        if (row_on && grp <= nB) {
-            const bool ends = grp == nB;
-            const int aa = 2 * s * (grp + 1), nq = mI / s;
-            const int aL = ends ? pe : aa, aU = ends ? 0 : aa;
-            const bool vL = ends ? (nq & 1) != 0 : true;
-            const bool vR = ends ? true : aa + s <= mI;
-            const int kL = ends ? nq * s : aa - s, kR = ends ? s : aa + s;
-            const int kLs = vL ? kL : 1, kRs = vR ? kR : 1;
-            double* rowL = row(aL, g);
-            double* rowU = row(aU, g);
-            double Lr[BB], Ur[BB];
-#pragma unroll
-            for (int c = 0; c < BB; ++c) { Lr[c] = rowL[oL + c]; Ur[c] = rowU[oU + c]; }
-            if (vL) {
-                double* rec = a.crf + (ch.nbase + ch.node(kL)) * 5 * B2 + 4 * B2 + g * BB;
-#pragma unroll
-                for (int c = 0; c < BB; ++c) rec[c] = Lr[c];
-            }
-            if (vR) {
-                double* rec = a.crf + (ch.nbase + ch.node(kR)) * 5 * B2 + 3 * B2 + g * BB;
-#pragma unroll
-                for (int c = 0; c < BB; ++c) rec[c] = Ur[c];
-            }
-            // the two sides one after the other (not interleaved): half the live registers
-            {
-                double nl[BB], dl[BB], yl = 0.0;
-#pragma unroll
-                for (int c = 0; c < BB; ++c) { nl[c] = 0.0; dl[c] = 0.0; }
-#pragma unroll
-                for (int m = 0; m < BB; ++m) {
-                    const double* eL = row(kLs, m);
-#pragma unroll
-                    for (int c = 0; c < BB; ++c) {
-                        nl[c] = tf_fma(-Lr[m], eL[oL + c], nl[c]);      // -L E_kL
-                        dl[c] = tf_fma(-Lr[m], eL[oU + c], dl[c]);      // -L F_kL
-                    }
-                    yl = tf_fma(-Lr[m], eL[oY], yl);
-                }
-                if (vL) {
-#pragma unroll
-                    for (int c = 0; c < BB; ++c) { rowL[oL + c] = nl[c]; rowL[oD + c] += dl[c]; }
-                    rowL[oY] += yl;
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                double nu[BB], du[BB], yu = 0.0;
-#pragma unroll
-                for (int c = 0; c < BB; ++c) { nu[c] = 0.0; du[c] = 0.0; }
-#pragma unroll
-                for (int m = 0; m < BB; ++m) {
-                    const double* eR = row(kRs, m);
-#pragma unroll
-                    for (int c = 0; c < BB; ++c) {
-                        nu[c] = tf_fma(-Ur[m], eR[oU + c], nu[c]);      // -U F_kR
-                        du[c] = tf_fma(-Ur[m], eR[oL + c], du[c]);      // -U E_kR
-                    }
-                    yu = tf_fma(-Ur[m], eR[oY], yu);
-                }
-                if (vR) {
-#pragma unroll
-                    for (int c = 0; c < BB; ++c) { rowU[oU + c] = nu[c]; rowU[oD + c] += du[c]; }
-                    rowU[oY] += yu;
-                }
-            }
-        }
-        __syncthreads();
-        TF_STAMP(a, stamp_i); ++stamp_i;
-    }
-
-    // ---- this chunk's share of the next level's rows
-    if (row_on && grp < 2) {
-        const int nn = grp == 0 ? ch.p : ch.pprev;
-        double* rec = a.Anext + ((int64_t)ch.e * a.Lnext.N + nn) * REC;
-        double* rr = a.rhsnext + ((int64_t)ch.e * a.Lnext.N + nn) * 2 * BB;
-        if (grp == 0) {
-            const double* r = row(pe, g);
-#pragma unroll
-            for (int c = 0; c < BB; ++c) { rec[0 * B2 + g * BB + c] = r[oL + c]; rec[1 * B2 + g * BB + c] = r[oD + c]; }
-            if (with_rhs) rr[g] = r[oY];
-        } else {
-            const double* r = row(0, g);
-#pragma unroll
-            for (int c = 0; c < BB; ++c) { rec[2 * B2 + g * BB + c] = r[oU + c]; rec[3 * B2 + g * BB + c] = r[oD + c]; }
-            if (with_rhs) rr[BB + g] = r[oY];
-        }
-    }
-    TF_STAMP(a, 20);
-    if (a.fold_top) {
-        // one chunk per system: what is left of rows 0 and pe couples the separator to
-        // itself only (TfTopArgs): invert their sum here, and solve for the first rhs
-        __syncthreads();
-        const bool on = grp == 0 && row_on;
-        const double* r0 = row(0, gq);
-        const double* rp = row(pe, gq);
-        double S[BB], A[BB + 1];
-#pragma unroll
-        for (int c = 0; c < BB; ++c) {
-            S[c] = rp[oL + c] + rp[oD + c] + r0[oU + c] + r0[oD + c];
-            A[c] = c == g ? 1.0 : 0.0;
-        }
-        A[BB] = rp[oY] + r0[oY];
-        const int myk = tf_gj_aug<BB, BB + 1, XW>(S, A, on, g, xch, ok);
-        if (on) {
-            const int nsys = L.Ptot;                 // P == 1
-#pragma unroll
-            for (int c = 0; c < BB; ++c) a.topAinv[(int64_t)(myk * BB + c) * nsys + ch.e] = A[c];
-        }
-        if (with_rhs) {
-            // ... and the back-substitution of this level (tfk_cr_bwd_coop): E_k, F_k and z_k
-            // are still in LDS; the y slots take the solution
-            __syncthreads();
-            if (on) {
-                const double x = A[BB];
-                a.topx[(int64_t)ch.e * BB + myk] = x;
-                a.x[(ch.nbase + ch.node(pe)) * BB + myk] = x;
-                row(pe, myk)[oY] = x;
-                row(0, myk)[oY] = ch.has_prev ? x : 0.0;
-            }
-            __syncthreads();
-            int s = 1;
-            while (2 * s <= mI) s <<= 1;
-            for (; s >= 1; s >>= 1) {
-                const int nA = (mI / s + 1) / 2;
-                if (grp < nA && row_on) {
-                    const int k = s * (2 * grp + 1);
-                    const int kl = k - s, kr = k + s <= mI ? k + s : pe;
-                    double* rk = row(k, g);
-                    double xk = rk[oY];
-#pragma unroll
-                    for (int m = 0; m < BB; ++m) {
-                        xk = tf_fma(-rk[oL + m], row(kl, m)[oY], xk);
-                        xk = tf_fma(-rk[oU + m], row(kr, m)[oY], xk);
-                    }
-                    // every lane of the group reads the neighbours' y before any lane of
-                    // another group overwrites them: positions written in this round (k) are
-                    // never read in it (kl, kr belong to later rounds)
-                    rk[oY] = xk;
-                    a.x[(ch.nbase + ch.node(k)) * BB + g] = xk;
-                }
-                __syncthreads();
-            }
-        }
-    }
-    if (!ok) *a.status = 1;
-    TF_STAMP(a, 21);
-    TF_STAMP_REAL(a, 31);
-}
-
 // ===========================================================================
-// Third version: one WAVEFRONT per node of the round, 8 wavefronts per chunk
+// One WAVEFRONT per node of the round, 8 (or 4) wavefronts per chunk
 // ===========================================================================
-// The versions above give a node 8 lanes (one per block row), so every pivot step is ~160
-// instructions of ONE wavefront (publish 4b+1 doubles, read them back, 4b+1 FMAs per lane):
-// measured 1300 cycles per pivot, 11 000 per round, and a level is 4 rounds of that.  Here
-// the 64 lanes of a wavefront share one node: lane (g, h) = (block row, column slice) holds
+// The 64 lanes of a wavefront share one node: lane (g, h) = (block row, column slice) holds
 // the augmented entries M[g][h + 8j] of  [L | D | U | y | I].  Per pivot step a lane
 // touches (4b+1)/8 ~ 4 entries; the pivot row index is wave-uniform (v_readlane), the pivot
 // row reaches the other rows with ds_bpermute (lane crossbar, no LDS memory, no barrier).
 // A chunk is a workgroup of 8 wavefronts = the 8 nodes that go in round 1 (later rounds
-// leave wavefronts idle at the barriers); LDS holds the chain as in version 2.
-// Same task lists, stored factors (a.crf, a.zt) and next-level rows as the other versions.
+// leave wavefronts idle at the barriers; 4 wavefronts on levels with more chunks than the GPU
+// holds at once).
 
 // 1/x by v_rcp_f64 (about 26 bits) and two Newton steps: within an ulp or two of the IEEE
 // quotient for normal x, a third of its instructions; 1/0 = inf like the division

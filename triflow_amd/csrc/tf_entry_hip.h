@@ -6,7 +6,7 @@
 
 #include "tf_coop_hip.h"
 #ifndef TF_CR_V2
-#define TF_CR_V2 3        // 0: first version (tf_coop_hip.h), 2 / 3: tf_cr2_hip.h
+#define TF_CR_V2 3        // 0: round-1 version (tf_coop_hip.h, 8 lanes per node), 3: tf_cr2_hip.h
 #endif
 #include "tf_cr2_hip.h"
 
@@ -218,7 +218,6 @@ tfk_cr_factor(TfLevelArgs a) {
     if constexpr (TF_B2 <= 2) tfk_crs_factor<TF_B2>(a);
     else if constexpr (TF_B2 <= 8) {
         if constexpr (TF_CR_V2 == 3) tfk_cr_factor_v3<TF_B2>(a);
-        else if constexpr (TF_CR_V2 == 2) tfk_cr_factor_v2<TF_B2>(a);
         else tfk_cr_factor_coop<TF_B2>(a);
     }
 }
