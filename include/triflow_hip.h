@@ -119,6 +119,12 @@ int tf_eval_repeat(tf_solver*, int32_t slot, int32_t with_j, int32_t reps, doubl
 int tf_get_F(tf_solver*, double* F /*[nsys][N*nvar], F[node*nvar+eq]*/);
 int tf_get_J(tf_solver*, double* Jvals /*[nsys][N][nnz], reference pattern order*/);
 
+/* the Jacobian values in the order of a caller's index list, uploaded once: out[t] = value-table
+ * entry map[t] = node * nnz + k of system 0 -- the data array of the csc_matrix that the
+ * reference's J function returns (compilers.py:303-331), gathered on the device */
+int tf_set_csc_map(tf_solver*, const int32_t* map, int64_t n);
+int tf_get_J_mapped(tf_solver*, double* out /*[n]*/);
+
 /* ---- seam #3: (I - c J) x = b with the Jacobian of the last tf_eval -------- */
 int tf_factor(tf_solver*, double c);
 int tf_solve(tf_solver*, const double* rhs_flat /*[nsys][N*nvar]*/, double* x_flat);

@@ -94,6 +94,8 @@ void launch(Module*, int kernel, unsigned gx, unsigned gy, unsigned block,
             a.partial[(int64_t)y * a.nblocks + b] = tfk_diffnorm_partial(a, (int)y, (int)b, 0, 1); } break;
     case TFK_PERM: { const auto& a = *(const TfPermArgs*)args;
         for (int64_t t = 0; t < nthreads; ++t) tfk_perm_elem(a, t); } break;
+    case TFK_GATHER: { const auto& a = *(const TfGatherArgs*)args;
+        for (int64_t t = 0; t < a.n; ++t) tfk_gather_elem(a, t); } break;
     case TFK_POKE: { const auto& a = *(const TfPokeArgs*)args;
         for (int64_t t = 0; t < nthreads; ++t) tfk_poke_elem(a, (int)t); } break;
     case TFK_DIRICHLET: { const auto& a = *(const TfDirichletArgs*)args;

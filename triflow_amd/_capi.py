@@ -63,6 +63,8 @@ SIGNATURES = {
     "tf_eval_repeat": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_double_p]),
     "tf_get_F": (C.c_int, [C.c_void_p, c_double_p]),
     "tf_get_J": (C.c_int, [C.c_void_p, c_double_p]),
+    "tf_set_csc_map": (C.c_int, [C.c_void_p, c_int32_p, C.c_int64]),
+    "tf_get_J_mapped": (C.c_int, [C.c_void_p, c_double_p]),
     "tf_factor": (C.c_int, [C.c_void_p, C.c_double]),
     "tf_solve": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "tf_matvec": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
@@ -298,6 +300,17 @@ class DeviceSolver:
         out = np.empty((self.nsys, self.N, max(self.nnz, 1)))
         self.lib.call("tf_get_J", self.handle, _dptr(out))
         return out[:, :, :self.nnz]
+
+    def set_csc_map(self, index_list):
+        """Value-table index (node * nnz + k) of every entry ``get_J_mapped`` is to return."""
+        m = np.ascontiguousarray(index_list, dtype=np.int32)
+        self.lib.call("tf_set_csc_map", self.handle, m.ctypes.data_as(c_int32_p), m.size)
+        self._csc_n = m.size
+
+    def get_J_mapped(self):
+        out = np.empty(self._csc_n)
+        self.lib.call("tf_get_J_mapped", self.handle, _dptr(out))
+        return out
 
     # ----------------------------------------------------------------- seam #3
     def factor(self, c):

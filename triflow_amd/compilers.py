@@ -270,10 +270,28 @@ class CscPattern:
         self.indices = (uniq % n).astype(np.int32 if n < 2 ** 31 else np.int64)
         ucols = uniq // n
         self.indptr = np.searchsorted(ucols, np.arange(n + 1)).astype(self.indices.dtype)
+        # for the device-side gather: the first table entry of every slot, then the further
+        # entries of slots with duplicates (clamped ghost columns: a handful of boundary entries)
+        # in table order, which is the order csc_matrix() sums them in
+        order = np.argsort(inverse, kind="stable")
+        first = np.ones(order.size, dtype=bool)
+        first[1:] = inverse[order[1:]] != inverse[order[:-1]]
+        self.extra_src = order[~first]
+        self.extra_slot = inverse[self.extra_src]
+        self.gather = np.concatenate([order[first], self.extra_src]).astype(np.int32) \
+            if key.size < 2 ** 31 else None
 
     def assemble(self, values):
         data = np.bincount(self.slot, weights=np.asarray(values).ravel(),
                            minlength=self.nslots)
+        return sps.csc_matrix((data, self.indices, self.indptr), shape=self.shape)
+
+    def from_gathered(self, gathered):
+        """``gathered``: the value table in the order of ``self.gather`` (device-side gather)."""
+        data = gathered[:self.nslots]
+        if self.extra_src.size:
+            data = data.copy()
+            np.add.at(data, self.extra_slot, gathered[self.nslots:])
         return sps.csc_matrix((data, self.indices, self.indptr), shape=self.shape)
 
 
@@ -398,7 +416,15 @@ class CompiledModel:
 
     def J_function(self, *args):
         solver, N, periodic = self._evaluate(args, with_j=True)
-        return self.pattern(N, periodic).assemble(solver.get_J()[0])
+        pat = self.pattern(N, periodic)
+        if pat.gather is None:
+            return pat.assemble(solver.get_J()[0])
+        # the CSC data array is gathered on the device in the pattern's order (index list
+        # uploaded once per solver): the download is the matrix, nothing is assembled on the host
+        if getattr(solver, "_csc_pattern", None) is not pat:
+            solver.set_csc_map(pat.gather)
+            solver._csc_pattern = pat
+        return pat.from_gathered(solver.get_J_mapped())
 
 
 def hip_compiler(model, backend=None):

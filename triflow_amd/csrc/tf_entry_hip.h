@@ -120,6 +120,9 @@ __global__ void __launch_bounds__(256) tfk_diffnorm(TfNormArgs a) {
 __global__ void __launch_bounds__(256) tfk_perm(TfPermArgs a) {
     tfk_perm_elem(a, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
+__global__ void __launch_bounds__(256) tfk_gather(TfGatherArgs a) {
+    tfk_gather_elem(a, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
 __global__ void __launch_bounds__(64) tfk_dirichlet(TfDirichletArgs a) {
     tfk_dirichlet_elem(a, TF_GID);
 }

@@ -418,6 +418,18 @@ TF_DEVICE void tfk_perm_elem(const TfPermArgs& a, int64_t t) {
     }
 }
 
+// Jacobian values in the order of a caller's index list (the CSC data array of the drop-in
+// J function: compilers.py:303-331 with the pattern computed once): entry map[t] = node * nnz + k
+// of system 0's value table
+TF_DEVICE void tfk_gather_elem(const TfGatherArgs& a, int64_t t) {
+    if (t >= a.n) return;
+    const int src = a.map[t];
+    const int g = src / a.nnz, k = src - g * a.nnz;
+    int p, i;
+    tf_locate(a.L, g, p, i);
+    a.out[t] = a.Jv[(int64_t)k * a.L.plane + tf_idx(a.L, p, i)];
+}
+
 // (a - b) of variable/system `vs` restricted to the slice of work item (blk, tid):
 // this thread's partial sum of squares (ord 2) or maximum (ord 0)
 TF_DEVICE double tfk_diffnorm_partial(const TfNormArgs& a, int vs, int blk, int tid, int nthreads) {

@@ -151,6 +151,8 @@ struct tf_solver {
     DevBuf dir_val, dir_val_post;   // values applied before the step (hook at t) / after (t+dt)
 
     DevBuf stamp_buf;              // diagnostic builds: 64 stamps per solver level (tf_debug_stamps)
+    int* csc_map = nullptr;        // tf_set_csc_map: value-table index of every CSC data slot
+    int64_t csc_n = 0;
     char* poke_buf = nullptr;      // scratch of tf_poke
     size_t poke_bytes = 0;
 
@@ -228,6 +230,7 @@ struct tf_solver {
         for (auto* e : event_pool) tfb::event_destroy(e);
         drop_graphs();
         if (poke_buf) tfb::dev_free(poke_buf);
+        if (csc_map) tfb::dev_free(csc_map);
         if (status) tfb::dev_free(status);
         if (dir_var) tfb::dev_free(dir_var);
         if (dir_node) tfb::dev_free(dir_node);
@@ -1008,6 +1011,33 @@ int tf_get_J(tf_solver* s, double* Jh) {
     require(s && Jh, "null argument");
     require(s->have_jac, "tf_get_J: no Jacobian evaluated yet");
     if (s->spec.nnz > 0) s->download_aos(s->Jv.p, Jh, s->spec.nnz);
+    TF_API_END
+}
+
+// The drop-in J function returns a scipy.sparse.csc_matrix (compilers.py:330-331): with the
+// pattern fixed, its data array is a gather of the value table.  The caller uploads the index
+// list once (entry t of the result = value-table entry map[t] = node * nnz + k, system 0) and
+// then downloads Jacobians in that order -- no assembly on the host.
+int tf_set_csc_map(tf_solver* s, const int32_t* map, int64_t n) {
+    TF_API_BEGIN
+    require(s && map && n >= 0, "tf_set_csc_map: arguments");
+    if (s->csc_map) { tfb::dev_free(s->csc_map); s->csc_map = nullptr; }
+    s->csc_map = (int*)tfb::dev_alloc(sizeof(int) * (size_t)std::max<int64_t>(n, 1));
+    s->bytes += (int64_t)sizeof(int) * n;
+    tfb::h2d(s->csc_map, map, sizeof(int) * (size_t)n, s->stream);
+    s->csc_n = n;
+    TF_API_END
+}
+int tf_get_J_mapped(tf_solver* s, double* out) {
+    TF_API_BEGIN
+    require(s && out, "null argument");
+    require(s->have_jac, "tf_get_J_mapped: no Jacobian evaluated yet");
+    require(s->csc_map != nullptr, "tf_get_J_mapped: no index list (tf_set_csc_map)");
+    s->ensure_staging((size_t)s->csc_n);
+    TfGatherArgs a;
+    a.L = s->L1; a.Jv = s->Jv.p; a.map = s->csc_map; a.out = s->staging.p; a.n = s->csc_n; a.nnz = s->spec.nnz;
+    s->launch(TFK_GATHER, tf_solver::cdiv(s->csc_n, 256), 1, 256, &a, sizeof(a));
+    tfb::d2h(out, s->staging.p, (size_t)s->csc_n * sizeof(double), s->stream);
     TF_API_END
 }
 
