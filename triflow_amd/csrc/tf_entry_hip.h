@@ -41,6 +41,13 @@ __global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_spmv(TfSpmvArgs a) {
     tfk_spmv_body<false>(a, TF_GID, blockIdx.y);
 }
 // the same product plus the backward-error monitor of the previous solve (TfSpmvArgs::mon_rhs)
+// running maximum kept as the bit pattern of a non-negative double.  The value only grows, so
+// a wavefront whose candidate is not above what is already there skips the atomic (tens of
+// thousands of same-address atomics otherwise: tfk_berr 72 -> 41 us, profiles/README.md).
+__device__ __forceinline__ void tf_raise_max(unsigned long long* red, unsigned long long bits) {
+    if (bits > __atomic_load_n(red, __ATOMIC_RELAXED)) atomicMax(red, bits);
+}
+
 __global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_spmv_mon(TfSpmvArgs a) {
     const double m = tfk_spmv_body<true>(a, TF_GID, blockIdx.y);
     {
@@ -51,7 +58,7 @@ __global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_spmv_mon(TfSpmvArgs a) {
             const unsigned long long o = __shfl_xor(bits, off, 64);
             bits = o > bits ? o : bits;
         }
-        if ((threadIdx.x & 63) == 0 && bits != 0) atomicMax((unsigned long long*)a.mon_red, bits);
+        if ((threadIdx.x & 63) == 0) tf_raise_max((unsigned long long*)a.mon_red, bits);
     }
 }
 
@@ -83,7 +90,7 @@ __global__ void __launch_bounds__(256) tfk_vec_maxabs(TfVecArgs a) {
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < (int)(blockDim.x >> 6); ++w) bits = part[w] > bits ? part[w] : bits;
-        atomicMax((unsigned long long*)a.red, bits);
+        tf_raise_max((unsigned long long*)a.red, bits);
     }
 }
 
@@ -96,7 +103,7 @@ __global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_berr(TfBerrArgs a) {
         const unsigned long long o = __shfl_xor(bits, off, 64);
         bits = o > bits ? o : bits;
     }
-    if ((threadIdx.x & 63) == 0 && bits != 0) atomicMax((unsigned long long*)a.red, bits);
+    if ((threadIdx.x & 63) == 0) tf_raise_max((unsigned long long*)a.red, bits);
 }
 
 // grid (nblocks, nvar*nsys): deterministic tree inside the block, one partial per block
