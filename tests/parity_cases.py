@@ -614,6 +614,34 @@ def check_unstable_factorisation_is_loud(backend):
     assert refined and omega < 1e-10
 
 
+def check_fused_stage_rhs(backend):
+    """Right-hand side of Rosenbrock stages i >= 1: tfk_sweep_f_stage_rhs (F of the stage state and
+    J @ sum gamma k from one window pass) against the two-kernel form it replaces
+    (tfk_sweep_f_stage + tfk_spmv): the same operations in the same order, so the same bits --
+    2, 3 and 4-stage tableaux, periodic and clamped with a Dirichlet hook, ragged chunk lengths."""
+    import os
+    from triflow_amd.ensemble import Ensemble
+    cases = [(3, "ROS2", None, 3001), (3, "ROS3PRL", None, 1777), (3, "RODASPR", None, 2500),
+             (1, "ROS3PRw", DEVICE_HOOKS["cfg1"], 203)]
+    for cfg, sch, hook, N in cases:
+        name, fd, pars, dt, _ = corpus.config_inputs(cfg, N)
+        m = device_model(name, backend)
+        fields = {k: v[None, :] for k, v in fd.items() if k != "x"}
+        out = []
+        for fuse in ("1", "0"):
+            os.environ["TRIFLOW_FUSE_STAGE"] = fuse
+            try:
+                ens = Ensemble(m, fd["x"], fields, pars, bool(pars["periodic"]), scheme=sch, hook=hook, nstate=2)
+            finally:
+                del os.environ["TRIFLOW_FUSE_STAGE"]
+            for k in range(12):                      # long enough to include a monitored step (n_factor = 4)
+                ens.step(dt)
+            ens.sync()
+            out.append(ens.state().copy())
+            ens.close()
+        assert np.isfinite(out[0]).all() and np.array_equal(out[0], out[1]), (cfg, sch)
+
+
 def check_row_monitor(backend):
     """Every Rosenbrock step measures the backward error of its factorisation inside the J @ v
     pass of stage 1 (quotients are only formed above 1e-12).  (i) A healthy factorisation reads 0,

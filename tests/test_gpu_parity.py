@@ -385,6 +385,10 @@ def test_row_monitor():
     pc.check_row_monitor(HIP)
 
 
+def test_fused_stage_rhs():
+    pc.check_fused_stage_rhs(HIP)
+
+
 def test_unstable_factorisation_is_loud():
     pc.check_unstable_factorisation_is_loud(HIP)
 

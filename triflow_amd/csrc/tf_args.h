@@ -54,6 +54,13 @@ struct TfSweepArgs {               // F / F+J stencil sweep, J @ v, A-row build
     double* bdf_prev;
     double bdf_c0, bdf_c1;
     int bdf_two_step;
+    // tfk_sweep_f_stage_rhs: the right-hand side of Rosenbrock stage i in the pass that evaluates
+    // its F:  rhs = cF*(fscale*F(U + sum_j kc_j k_j)) + cA*(J @ (sum_j gc_j k_j)), the operations of
+    // tfk_sweep_f_stage followed by tfk_spmv's stage form, in their order (schemes.py:152-160).
+    // F itself is not stored; Jv is read (the entries that are not node-independent).
+    double* stage_rhs;
+    double gc[TF_MAX_TERMS];
+    double cF, cA;
 };
 
 struct TfSpmvArgs {                // y = scale * J @ v  (clamped/wrapped columns)
@@ -226,7 +233,8 @@ enum TfKernel {
     TFK_L1_FACTOR, TFK_L1_SOLVE, TFK_L1_ASM_MAT, TFK_L1_ASM_RHS, TFK_L1_BACKSUB,
     TFK_BT_LU, TFK_BT_SPIKE, TFK_BT_RHS, TFK_BT_ASM_MAT, TFK_BT_ASM_RHS, TFK_BT_BACKSUB,
     TFK_TOP_FACTOR, TFK_TOP_SOLVE, TFK_BERR, TFK_DIFFNORM, TFK_L1_FACTOR_RHS, TFK_SWEEP_F_STAGE,
-    TFK_CR_FACTOR, TFK_CR_FWD, TFK_CR_BWD, TFK_POKE, TFK_SWEEP_FJ_THETA, TFK_SWEEP_FJ_BDF2, TFK_SPMV_MON, TFK_GATHER, TFK_COUNT
+    TFK_CR_FACTOR, TFK_CR_FWD, TFK_CR_BWD, TFK_POKE, TFK_SWEEP_FJ_THETA, TFK_SWEEP_FJ_BDF2, TFK_SPMV_MON, TFK_GATHER,
+    TFK_SWEEP_F_STAGE_RHS, TFK_COUNT
 };
 #define TF_KERNEL_NAMES { \
     "tfk_sweep_f", "tfk_sweep_fj", "tfk_spmv", "tfk_vec", "tfk_vec_maxabs", "tfk_perm", "tfk_dirichlet", \
@@ -234,4 +242,4 @@ enum TfKernel {
     "tfk_bt_lu", "tfk_bt_spike", "tfk_bt_rhs", "tfk_bt_asm_mat", "tfk_bt_asm_rhs", "tfk_bt_backsub", \
     "tfk_top_factor", "tfk_top_solve", "tfk_berr", "tfk_diffnorm", "tfk_l1_factor_rhs", "tfk_sweep_f_stage", \
     "tfk_cr_factor", "tfk_cr_fwd", "tfk_cr_bwd", "tfk_poke", "tfk_sweep_fj_theta", "tfk_sweep_fj_bdf2", \
-    "tfk_spmv_mon", "tfk_gather" }
+    "tfk_spmv_mon", "tfk_gather", "tfk_sweep_f_stage_rhs" }

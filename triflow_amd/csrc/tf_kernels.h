@@ -119,7 +119,7 @@ struct TfJUniform {
 // 1. F / F+J stencil sweep                       (compilers.py:227-332)
 // ===========================================================================
 // grid: x over chunks (all systems), y over segments of TF_SEG nodes.
-template <bool WITH_J, bool STAGE = false, bool THETA = false, bool BDF = false>
+template <bool WITH_J, bool STAGE = false, bool THETA = false, bool BDF = false, bool STAGE_RHS = false>
 TF_DEVICE void tfk_sweep_body(const TfSweepArgs& a, int pg, int seg) {
     const TfLayout& L = a.L;
     if (pg >= L.Ptot) return;
@@ -143,12 +143,29 @@ TF_DEVICE void tfk_sweep_body(const TfSweepArgs& a, int pg, int seg) {
         for (int t = 1; t < a.nterms; ++t) acc = acc + a.kc[t] * a.kx[t][(int64_t)f * L.plane + s];
         return u + acc;
     };
+    // STAGE_RHS: one load of every k_j serves the stage state and v = sum_j gamma_ij k_j
+    auto ld2 = [&](int f, int ii, double& v) -> double {
+        const int64_t q = (int64_t)f * L.plane +
+            ((ii >= 0 && ii < len) ? tf_idx(L, pg, ii) : tf_nbr(L, e, p, len, 0, ii));
+        const double u = a.fields[q];
+        double k = a.kx[0][q];
+        double acc = a.kc[0] * k, g = a.gc[0] * k;
+        for (int t = 1; t < a.nterms; ++t) { k = a.kx[t][q]; acc = acc + a.kc[t] * k; g = g + a.gc[t] * k; }
+        v = g;
+        return u + acc;
+    };
 
     double w[TF_NF][TF_W];
+    double wv[STAGE_RHS ? TF_NVAR : 1][TF_W];
+    TfJUniform ju;
+    if (STAGE_RHS) ju.init(a.parsca, a.dx, L.nsys, e);
 #pragma unroll
     for (int f = 0; f < TF_NF; ++f)
 #pragma unroll
-        for (int o = 1; o < TF_W; ++o) w[f][o] = ld(f, i0 - TF_MP + o - 1);
+        for (int o = 1; o < TF_W; ++o) {
+            if (STAGE_RHS && f < TF_NVAR) w[f][o] = ld2(f, i0 - TF_MP + o - 1, wv[STAGE_RHS ? f : 0][o]);
+            else w[f][o] = ld(f, i0 - TF_MP + o - 1);
+        }
 
 #pragma unroll
     for (int j = 0; j < TF_SEG; ++j) {
@@ -158,7 +175,13 @@ TF_DEVICE void tfk_sweep_body(const TfSweepArgs& a, int pg, int seg) {
             for (int f = 0; f < TF_NF; ++f) {
 #pragma unroll
                 for (int o = 0; o < TF_W - 1; ++o) w[f][o] = w[f][o + 1];
-                w[f][TF_W - 1] = ld(f, i + TF_MP);
+                if (STAGE_RHS && f < TF_NVAR) {
+#pragma unroll
+                    for (int o = 0; o < TF_W - 1; ++o) wv[STAGE_RHS ? f : 0][o] = wv[STAGE_RHS ? f : 0][o + 1];
+                    w[f][TF_W - 1] = ld2(f, i + TF_MP, wv[STAGE_RHS ? f : 0][TF_W - 1]);
+                } else {
+                    w[f][TF_W - 1] = ld(f, i + TF_MP);
+                }
             }
             const int64_t s = tf_idx(L, pg, i);
 #pragma unroll
@@ -168,6 +191,21 @@ TF_DEVICE void tfk_sweep_body(const TfSweepArgs& a, int pg, int seg) {
             if (TF_USES_X) xc = a.xcoord[s];
             double Fo[TF_NVAR];
             tf_eval_F(w, par, dx, xc, Fo);
+            if (STAGE_RHS) {
+                double acc[TF_NVAR];
+#pragma unroll
+                for (int v = 0; v < TF_NVAR; ++v) acc[v] = 0.0;
+#pragma unroll
+                for (int k = 0; k < TF_NNZ; ++k) {       // tfk_spmv_body, scale = 1
+                    const double jv = 1.0 * (TF_JU(k) ? ju.v[k] : a.Jv[(int64_t)k * L.plane + s]);
+                    acc[tf_pat_eq[k]] = acc[tf_pat_eq[k]] +
+                        jv * wv[STAGE_RHS ? tf_pat_var[k] : 0][tf_pat_off[k] + TF_MP];
+                }
+#pragma unroll
+                for (int v = 0; v < TF_NVAR; ++v)
+                    a.stage_rhs[(int64_t)v * L.plane + s] = a.cF * (a.fscale * Fo[v]) + a.cA * acc[v];
+                continue;
+            }
 #pragma unroll
             for (int v = 0; v < TF_NVAR; ++v) TF_STORE_STREAM(&a.F[(int64_t)v * L.plane + s], a.fscale * Fo[v]);
             if (WITH_J) {

@@ -384,15 +384,40 @@ struct tf_solver {
     }
 
     // y = cF*F + cA*(J @ sum_t vc_t vx_t): stage right-hand side of a ROW scheme in one pass
+    // (every monitor_every-th factorisation: the magnitudes make the pass 40 % slower)
+    bool monitor_due(const double* monitor_rhs, int nterms, const double* vc) const {
+        return monitor_rhs && nterms == 1 && vc[0] != 0.0 && refine < 0 &&
+               (refine == -2 || n_factor % monitor_every == monitor_every / 2);
+    }
+    // Right-hand side of Rosenbrock stage i >= 1,  dt*F(U + sum_j alpha_ij k_j) + dt*(J @ sum_j gamma_ij k_j):
+    // one pass (tfk_sweep_f_stage_rhs) that evaluates F from the window and multiplies J by the other
+    // combination of the same k_j loads.  When the monitor is due, the two-kernel form runs
+    // (tfk_sweep_f_stage, tfk_spmv_mon): same operations, same bits.
+    bool fuse_stage = true;
+    void stage_rhs(const double* Uin, int nterms, const double* const* ks, const double* ac,
+                   const double* gc, double dt, double* y, const double* monitor_rhs) {
+        if (!fuse_stage || monitor_due(monitor_rhs, nterms, gc)) {
+            sweep(Uin, false, nterms, ks, ac, 1.0, Wstage.p);
+            spmv_stage(nterms, ks, gc, Wstage.p, dt, dt, y, monitor_rhs);
+            return;
+        }
+        TfSweepArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.nterms = nterms; a.fscale = 1.0;
+        for (int t = 0; t < nterms; ++t) { a.kx[t] = ks[t]; a.kc[t] = ac[t]; a.gc[t] = gc[t]; }
+        a.L = L1; a.fields = Uin; a.helpers = helpers.p; a.parvec = parvec.p; a.parsca = parsca.p;
+        a.dx = dx.p; a.xcoord = xcoord.p; a.F = Wstage.p; a.Jv = Jv.p;
+        a.stage_rhs = y; a.cF = dt; a.cA = dt;
+        unsigned gx = sweep_gx(), gy = cdiv(L1.M, spec.seg);
+        launch(TFK_SWEEP_F_STAGE_RHS, gx, gy, spec.sweep_block, &a, sizeof(a));
+    }
     // monitor_rhs != NULL (first stage product of a Rosenbrock step, one term g*k0): the same pass
     // measures the backward error of the solve that produced k0 from monitor_rhs (red[4])
     void spmv_stage(int nterms, const double* const* vx, const double* vc, const double* Fp,
                     double cF, double cA, double* y, const double* monitor_rhs = nullptr) {
         TfSpmvArgs a;
         std::memset(&a, 0, sizeof(a));
-        // (every monitor_every-th factorisation: the magnitudes make this pass 60 % slower)
-        const bool mon = monitor_rhs && nterms == 1 && vc[0] != 0.0 && refine < 0 &&
-                         (refine == -2 || n_factor % monitor_every == monitor_every / 2);
+        const bool mon = monitor_due(monitor_rhs, nterms, vc);
         if (mon) {
             a.mon_rhs = monitor_rhs; a.mon_c = factor_c; a.mon_inv_g = 1.0 / vc[0]; a.mon_red = red.p + 4;
             monitored = true;
@@ -672,6 +697,7 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
     s->stream = tfb::stream_create();
     s->graphs_on = tfb::graphs_supported() && (int64_t)N * nsys <= 50000;
     if (const char* v = getenv("TRIFLOW_GRAPHS")) s->graphs_on = tfb::graphs_supported() && atoi(v) != 0;
+    if (const char* v = getenv("TRIFLOW_FUSE_STAGE")) s->fuse_stage = atoi(v) != 0;      // A/B runs
 
     // ---- level plan: chunk levels until a single chunk is left, then the top block.
     // Reduced levels: walks over chunks of m_upper nodes, or -- where the back end has
@@ -1097,12 +1123,11 @@ void step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns, con
         if (i > 0) {
             // F(U + sum_j alpha_ij k_j): the stage state is formed inside the sweep.  It goes to a
             // buffer of its own: F keeps dt*F(U), the right-hand side of stage 0, for the monitor
-            for (int j = 0; j < i; ++j) { ks[j] = s->K[j].p; cs[j] = alpha[i * ns + j]; }
-            s->sweep(Uin, false, i, ks, cs, 1.0, s->Wstage.p);
-            // dt*F + dt*(J @ sum_j gamma_ij k_j) in one pass over J; for i == 1 the pass also
-            // measures the backward error of the stage-0 solve (k0 from dt*F(U))
-            for (int j = 0; j < i; ++j) cs[j] = gamma[i * ns + j];
-            s->spmv_stage(i, ks, cs, s->Wstage.p, dt, dt, s->Wrhs.p, i == 1 ? s->F.p : nullptr);
+            // ... plus dt*(J @ sum_j gamma_ij k_j), in the same pass; for i == 1 the pass (every 8th
+            // factorisation) also measures the backward error of the stage-0 solve (k0 from dt*F(U))
+            double gs[TF_MAX_TERMS];
+            for (int j = 0; j < i; ++j) { ks[j] = s->K[j].p; cs[j] = alpha[i * ns + j]; gs[j] = gamma[i * ns + j]; }
+            s->stage_rhs(Uin, i, ks, cs, gs, dt, s->Wrhs.p, i == 1 ? s->F.p : nullptr);
         }
         if (i == 0) s->factor(gamma[0] * dt, s->F.p, s->K[0].p);      // factorise + first stage
         else s->solve(s->Wrhs.p, s->K[i].p);
