@@ -66,7 +66,7 @@ void launch(Module*, int kernel, unsigned gx, unsigned gy, unsigned block,
     case TFK_SWEEP_F_STAGE: { const auto& a = *(const TfSweepArgs*)args;
         for (unsigned y = 0; y < gy; ++y) for (int64_t t = 0; t < nthreads; ++t) tfk_sweep_body<false, true>(a, (int)t, (int)y); } break;
     case TFK_SWEEP_F_STAGE_RHS: { const auto& a = *(const TfSweepArgs*)args;
-        for (unsigned y = 0; y < gy; ++y) for (int64_t t = 0; t < nthreads; ++t) tfk_sweep_body<false, true, false, false, true>(a, (int)t, (int)y); } break;
+        for (unsigned y = 0; y < gy; ++y) for (int64_t t = 0; t < nthreads; ++t) tfk_sweep_body<false, true, false, false, true, TF_STAGE_SEG>(a, (int)t, (int)y); } break;
     case TFK_SWEEP_FJ_BDF2: { const auto& a = *(const TfSweepArgs*)args;
         for (unsigned y = 0; y < gy; ++y) for (int64_t t = 0; t < nthreads; ++t) tfk_sweep_body<true, false, false, true>(a, (int)t, (int)y); } break;
     case TFK_SWEEP_FJ_THETA: { const auto& a = *(const TfSweepArgs*)args;

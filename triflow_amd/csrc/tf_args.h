@@ -221,6 +221,11 @@ struct TfTopArgs {                 // final 1-node system per ensemble member
     int aos;                       // 1: A [sys][4][b][b], rhs [sys][2][b], x [sys][b] (cyclic-reduction levels below)
 };
 
+// nodes per thread of tfk_sweep_f_stage_rhs (the other sweeps: TF_SEG of the code object, 4 or 8).
+// Two register windows per variable make its ghost rows twice as expensive: 8 nodes per thread
+// read 152 MB where 4 read 176 MB (config 3; 43 against 51 us per launch, profiles/r02_ab_runs.txt)
+#define TF_STAGE_SEG 8
+
 // nodes per chunk of a cyclic-reduction level (one wavefront: 8 nodes x 8 lanes per round)
 #define TF_CR_MAXLEN 16
 // ... and of the scalar variant (b <= 2: one thread per node, 256-thread workgroups)

@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_sweep_f_stage(TfSweepArgs 
     tfk_sweep_body<false, true>(a, TF_GID, blockIdx.y);
 }
 __global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_sweep_f_stage_rhs(TfSweepArgs a) {
-    tfk_sweep_body<false, true, false, false, true>(a, TF_GID, blockIdx.y);
+    tfk_sweep_body<false, true, false, false, true, TF_STAGE_SEG>(a, TF_GID, blockIdx.y);
 }
 __global__ void TF_SWEEP_ATTR __launch_bounds__(TF_SWEEP_BLOCK) tfk_sweep_fj(TfSweepArgs a) {
     tfk_sweep_body<true>(a, TF_GID, blockIdx.y);

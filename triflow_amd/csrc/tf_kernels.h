@@ -119,13 +119,14 @@ struct TfJUniform {
 // 1. F / F+J stencil sweep                       (compilers.py:227-332)
 // ===========================================================================
 // grid: x over chunks (all systems), y over segments of TF_SEG nodes.
-template <bool WITH_J, bool STAGE = false, bool THETA = false, bool BDF = false, bool STAGE_RHS = false>
+template <bool WITH_J, bool STAGE = false, bool THETA = false, bool BDF = false, bool STAGE_RHS = false,
+          int SEG = TF_SEG>
 TF_DEVICE void tfk_sweep_body(const TfSweepArgs& a, int pg, int seg) {
     const TfLayout& L = a.L;
     if (pg >= L.Ptot) return;
     const int e = pg / L.P, p = pg - e * L.P;
     const int len = tf_len(L, p);
-    const int i0 = seg * TF_SEG;
+    const int i0 = seg * SEG;
     if (i0 >= len) return;
 
     double par[TF_NPAR > 0 ? TF_NPAR : 1];
@@ -168,7 +169,7 @@ TF_DEVICE void tfk_sweep_body(const TfSweepArgs& a, int pg, int seg) {
         }
 
 #pragma unroll
-    for (int j = 0; j < TF_SEG; ++j) {
+    for (int j = 0; j < SEG; ++j) {
         const int i = i0 + j;
         if (i < len) {
 #pragma unroll

@@ -408,7 +408,7 @@ struct tf_solver {
         a.L = L1; a.fields = Uin; a.helpers = helpers.p; a.parvec = parvec.p; a.parsca = parsca.p;
         a.dx = dx.p; a.xcoord = xcoord.p; a.F = Wstage.p; a.Jv = Jv.p;
         a.stage_rhs = y; a.cF = dt; a.cA = dt;
-        unsigned gx = sweep_gx(), gy = cdiv(L1.M, spec.seg);
+        unsigned gx = sweep_gx(), gy = cdiv(L1.M, TF_STAGE_SEG);
         launch(TFK_SWEEP_F_STAGE_RHS, gx, gy, spec.sweep_block, &a, sizeof(a));
     }
     // monitor_rhs != NULL (first stage product of a Rosenbrock step, one term g*k0): the same pass
