@@ -177,10 +177,14 @@ def main():
     # rehearsal on a one-GPU box: TRIFLOW_BENCH_BACKEND=gloo puts every rank on GPU 0
     backend = os.environ.get("TRIFLOW_BENCH_BACKEND", "nccl")
     device_index = local_rank if backend == "nccl" else 0
-    if world > 1:
+    # TRIFLOW_BENCH_FORCE_DIST=1: a one-rank run still goes through the process group (RCCL init,
+    # broadcast, all-gather, barrier) -- the N > 1 code path on a one-GPU box (tests/test_gpu_parity.py)
+    multi = world > 1 or os.environ.get("TRIFLOW_BENCH_FORCE_DIST") == "1"
+    if multi:
         import torch.distributed as dist
         torch.cuda.set_device(device_index)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")          # (torch.distributed.run sets both)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", device_index))
@@ -205,7 +209,7 @@ def main():
 
     def barrier():
         ens.sync()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -240,7 +244,7 @@ def main():
         solver.timing(False)
     blocks = np.asarray(blocks)
     seen = None
-    if world > 1:
+    if multi:
         tdev = "cuda" if backend == "nccl" else "cpu"
         tb = torch.tensor(blocks, dtype=torch.float64, device=tdev)
         gathered = [torch.zeros_like(tb) for _ in range(world)]
@@ -310,7 +314,7 @@ def main():
                                              "SURVEY's F+J formula, 'fused_frac' by the bytes it moves" % sweep_kernel)
         if report:
             out["kernels_ms_per_step"] = {k: round(v[0] / nprof, 5) for k, v in report.items()}
-        if world > 1:
+        if multi:
             devices = [s["device"] for s in seen]
             out["backend"] = "%s (%s)" % (backend, "RCCL over xGMI" if backend == "nccl" else "rehearsal")
             out["ranks_seen"] = len(seen)
@@ -329,7 +333,7 @@ def main():
             if workers > 1:
                 out["cpu_baseline_members"] = cpu_baseline(args.config, N, scheme, workers=workers)
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

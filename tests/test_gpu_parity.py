@@ -426,6 +426,24 @@ def test_examples_run(script, args):
         assert "t: 2.5" in res.stdout and res.stdout.count("iteration") == 5, res.stdout
 
 
+def test_bench_process_group_one_rank():
+    """The N > 1 leg of bench.py -- RCCL process group with the device bound, parameter-table
+    broadcast, barriers around the timed blocks, all-gather of the block times and of the device
+    identities -- executed with the one rank a one-GPU box allows (TRIFLOW_BENCH_FORCE_DIST=1)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TRIFLOW_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29591",
+               RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--nodes", "20000",
+                          "--steps", "5", "--warmup", "2", "--repeats", "3", "--no-cpu-baseline", "--plain"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["backend"].startswith("nccl") and line["ranks_seen"] == 1 and len(line["devices_seen"]) == 1
+    assert line["n_gpus"] == 1 and line["value"] > 0 and len(line["steps_per_s_per_rank"]) == 1
+    assert abs(line["steps_per_s_per_rank"][0] - line["value"]) <= 1e-2 * line["value"]
+
+
 def test_python_hook_stays_resident():
     pc.check_python_hook_stays_resident(HIP)
 

@@ -26,7 +26,7 @@ def broadcast_table(table, src=0):
     (RCCL when the process group is 'nccl', Gloo on CPU)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return np.asarray(table, dtype=np.float64)
     device = "cuda" if dist.get_backend() == "nccl" else "cpu"
     t = torch.as_tensor(np.ascontiguousarray(table, dtype=np.float64)).to(device)
