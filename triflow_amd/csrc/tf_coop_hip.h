@@ -715,6 +715,25 @@ __device__ __forceinline__ void tfk_cr_factor_coop(const TfLevelArgs& a) {
     if (!ok) *a.status = 1;
 }
 
+// One block row (BB doubles, contiguous) of a stored record.  Records start at multiples of
+// 5*BB*BB doubles and a row at g*BB, so for even BB a row is 16-byte aligned and goes as
+// BB/2 x global_load_dwordx4 instead of BB x dwordx2 (half the requests of the solve kernels).
+template <int BB>
+__device__ __forceinline__ void tf_load_row(const double* p, bool on, double (&dst)[BB]) {
+    if constexpr (BB % 2 == 0) {
+        const double2* q = reinterpret_cast<const double2*>(__builtin_assume_aligned(p, 16));
+#pragma unroll
+        for (int m = 0; m < BB / 2; ++m) {
+            const double2 v = q[m];
+            dst[2 * m] = on ? v.x : 0.0;
+            dst[2 * m + 1] = on ? v.y : 0.0;
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < BB; ++m) dst[m] = on ? p[m] : 0.0;
+    }
+}
+
 // Rows of the stored reduction that a lane needs in round r are known up front
 // (one task per group and phase), so the solve kernels request all of them
 // before the first round: one memory latency per launch instead of one per round.
@@ -749,12 +768,9 @@ __device__ __forceinline__ void tfk_cr_fwd_coop(const TfLevelArgs& a) {
         const double* rk = a.crf + (ch.nbase + ch.node(onA ? k : 1)) * 5 * B2 + g * BB;
         const double* rl = a.crf + (ch.nbase + ch.node(vL ? kL : 1)) * 5 * B2 + 4 * B2 + g * BB;
         const double* rr = a.crf + (ch.nbase + ch.node(vR ? kR : 1)) * 5 * B2 + 3 * B2 + g * BB;
-#pragma unroll
-        for (int m = 0; m < BB; ++m) {
-            Di[r][m] = onA ? rk[m] : 0.0;
-            Lb[r][m] = vL ? rl[m] : 0.0;
-            Ua[r][m] = vR ? rr[m] : 0.0;
-        }
+        tf_load_row<BB>(rk, onA, Di[r]);
+        tf_load_row<BB>(rl, vL, Lb[r]);
+        tf_load_row<BB>(rr, vR, Ua[r]);
     }
     __syncthreads();
     for (int i = tid; i < (len + 1) * BB; i += 64) {
@@ -861,11 +877,8 @@ __device__ __forceinline__ void tfk_cr_bwd_coop(const TfLevelArgs& a) {
         const bool on = s <= mI && grp < nA && row_on;
         const int k = on ? s * (2 * grp + 1) : 1;
         const double* rec = a.crf + (ch.nbase + ch.node(k)) * 5 * B2 + g * BB;
-#pragma unroll
-        for (int m = 0; m < BB; ++m) {
-            Er[r][m] = on ? rec[1 * B2 + m] : 0.0;
-            Fr[r][m] = on ? rec[2 * B2 + m] : 0.0;
-        }
+        tf_load_row<BB>(rec + 1 * B2, on, Er[r]);
+        tf_load_row<BB>(rec + 2 * B2, on, Fr[r]);
         zk[r] = on ? a.zt[(ch.nbase + ch.node(k)) * BB + g] : 0.0;
     }
     if (row_on && grp == 0) {
