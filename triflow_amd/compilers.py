@@ -41,7 +41,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "lib", "libtriflow_hip.so")
 CACHE_DIR = os.path.join(PKG_DIR, "_cache")
 GPU_ARCH = "gfx950"
-# TRIFLOW_HIPCC_EXTRA: e.g. "-DTF_CR_V2=0 -DTF_BACKSUB_DEPTH=1" (A/B runs of kernel variants)
+# TRIFLOW_HIPCC_EXTRA: e.g. "-DTF_USE_JUNIFORM=0 -DTF_BACKSUB_DEPTH=1" (A/B runs of kernel variants)
 HIPCC_FLAGS = [*os.environ.get("TRIFLOW_HIPCC_OPT", "-O3").split(), "-std=c++17",
                "-ffp-contract=off", "--offload-arch=" + GPU_ARCH,
                *os.environ.get("TRIFLOW_HIPCC_EXTRA", "").split()]

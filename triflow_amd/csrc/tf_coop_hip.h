@@ -497,223 +497,9 @@ __device__ __forceinline__ int tf_gj_coop(double (&S)[BB], double (&INV)[BB], bo
     return myk;
 }
 
-template <int BB>
-__device__ __forceinline__ void tfk_cr_factor_coop(const TfLevelArgs& a) {
-    typedef TfCr<BB> C;
-    constexpr int G = C::G, NGRP = C::NGRP, NPOS = C::NPOS, B2 = BB * BB, REC = 4 * B2;
-    const TfLayout& L = a.L;
-    const TfCrChunk<BB> ch(L);
-    const int tid = threadIdx.x, grp = tid / G, g = tid % G;
-    const bool row_on = g < BB;
-    const int gq = row_on ? g : 0;
-    const int mI = ch.mI, pe = ch.pe, len = ch.len;
-    const bool with_rhs = a.cr_rhs != 0;
-
-    // rows of the chain as records [pos][L, D, U, second part of D][b][b]
-    __shared__ __attribute__((aligned(16))) double sRec[NPOS * REC];
-    __shared__ double sYr[NPOS * 2 * BB], sY[NPOS][BB], sZ[NPOS][BB];
-    __shared__ double sX[NGRP * 2 * G * (2 * BB + 1)];
-    auto rL = [&](int pos) { return sRec + pos * REC; };
-    auto rD = [&](int pos) { return sRec + pos * REC + B2; };
-    auto rU = [&](int pos) { return sRec + pos * REC + 2 * B2; };
-
-    // ---- load: the records of a chunk are contiguous (natural node order)
-    {
-        const double2* src = (const double2*)(a.Ablk + (ch.nbase + ch.start) * REC);
-        double2* dst = (double2*)(sRec + REC);
-        const int n2 = len * REC / 2;
-#pragma unroll
-        for (int it = 0; it < (C::MAXLEN * REC / 2 + 63) / 64; ++it) {
-            const int i = it * 64 + tid;
-            if (i < n2) dst[i] = src[i];
-        }
-        const double* prev = a.Ablk + (ch.nbase + ch.gprev) * REC;
-        for (int i = tid; i < REC; i += 64)
-            sRec[i] = (ch.has_prev && i >= 2 * B2 && i < 3 * B2) ? prev[i] : 0.0;
-        if (with_rhs) {
-            const double* ys = a.rhs + (ch.nbase + ch.start) * 2 * BB;
-            for (int i = tid; i < len * 2 * BB; i += 64) sYr[2 * BB + i] = ys[i];
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < len * B2; i += 64) {       // D = both parts
-        const int pos = 1 + i / B2, rc = i - (pos - 1) * B2;
-        sRec[pos * REC + B2 + rc] += sRec[pos * REC + 3 * B2 + rc];
-    }
-    for (int i = tid; i < (len + 1) * BB; i += 64) {
-        const int pos = i / BB, r = i - pos * BB;
-        sY[pos][r] = (with_rhs && pos > 0) ? sYr[pos * 2 * BB + r] + sYr[pos * 2 * BB + BB + r] : 0.0;
-    }
-    if (!L.periodic) {                               // no neighbour beyond the ends of a system
-        if (ch.start == 0) for (int i = tid; i < B2; i += 64) rL(1)[i] = 0.0;
-        if (ch.start + len == L.N) for (int i = tid; i < B2; i += 64) rU(pe)[i] = 0.0;
-    }
-    __syncthreads();
-
-    bool ok = true;
-    for (int s = 1; s <= mI; s <<= 1) {
-        // ---- phase A: invert the diagonal blocks of the nodes that go this round
-        const int nA = (mI / s + 1) / 2;             // <= 8: one per group
-        {
-            const bool on = grp < nA && row_on;
-            const int k = grp < nA ? s * (2 * grp + 1) : 1;
-            double S[BB], INV[BB];
-#pragma unroll
-            for (int c = 0; c < BB; ++c) S[c] = rD(k)[gq * BB + c];
-            const int myk = tf_gj_coop<BB, G>(S, INV, on, g, sX + grp * 2 * G * (2 * BB + 1), ok);
-            // this lane holds row myk of D_k^-1
-            double Er[BB], Fr[BB], z = 0.0;
-#pragma unroll
-            for (int c = 0; c < BB; ++c) { Er[c] = 0.0; Fr[c] = 0.0; }
-#pragma unroll
-            for (int m = 0; m < BB; ++m) {
-#pragma unroll
-                for (int c = 0; c < BB; ++c) {
-                    Er[c] = tf_fma(INV[m], rL(k)[m * BB + c], Er[c]);
-                    Fr[c] = tf_fma(INV[m], rU(k)[m * BB + c], Fr[c]);
-                }
-                z = tf_fma(INV[m], sY[k][m], z);
-            }
-            if (on) {
-                double* rec = a.crf + (ch.nbase + ch.node(k)) * 5 * B2;
-#pragma unroll
-                for (int c = 0; c < BB; ++c) {
-                    rec[0 * B2 + myk * BB + c] = INV[c];
-                    rec[1 * B2 + myk * BB + c] = Er[c];
-                    rec[2 * B2 + myk * BB + c] = Fr[c];
-                }
-                if (with_rhs) a.zt[(ch.nbase + ch.node(k)) * BB + myk] = z;
-            }
-            __syncthreads();                         // every lane has read L_k, U_k, y_k
-            if (on) {
-#pragma unroll
-                for (int c = 0; c < BB; ++c) { rL(k)[myk * BB + c] = Er[c]; rU(k)[myk * BB + c] = Fr[c]; }
-                sZ[k][myk] = z;
-            }
-        }
-        __syncthreads();
-        // ---- phase B: the neighbours take the update, one task per group.  Interior
-        //      a = 2s(t+1): its L side lost kL = a-s, its U side loses kR = a+s (if there).
-        //      Last task: the L side of the own separator (pe) and the U side of position 0.
-        const int nB = mI / (2 * s);                 // <= 7
-        if (row_on && grp <= nB) {
-            const bool ends = grp == nB;
-            const int aa = 2 * s * (grp + 1), nq = mI / s;
-            const int aL = ends ? pe : aa, aU = ends ? 0 : aa;
-            const bool vL = ends ? (nq & 1) != 0 : true;
-            const bool vR = ends ? true : aa + s <= mI;
-            const int kL = ends ? nq * s : aa - s, kR = ends ? s : aa + s;
-            const int kLs = vL ? kL : 1, kRs = vR ? kR : 1;
-            double Lr[BB], Ur[BB];
-#pragma unroll
-            for (int c = 0; c < BB; ++c) { Lr[c] = rL(aL)[g * BB + c]; Ur[c] = rU(aU)[g * BB + c]; }
-            if (vL) {
-                double* rec = a.crf + (ch.nbase + ch.node(kL)) * 5 * B2 + 4 * B2 + g * BB;
-#pragma unroll
-                for (int c = 0; c < BB; ++c) rec[c] = Lr[c];
-            }
-            if (vR) {
-                double* rec = a.crf + (ch.nbase + ch.node(kR)) * 5 * B2 + 3 * B2 + g * BB;
-#pragma unroll
-                for (int c = 0; c < BB; ++c) rec[c] = Ur[c];
-            }
-            double nl[BB], dl[BB], nu[BB], du[BB], yl = 0.0, yu = 0.0;
-#pragma unroll
-            for (int c = 0; c < BB; ++c) { nl[c] = 0.0; dl[c] = 0.0; nu[c] = 0.0; du[c] = 0.0; }
-#pragma unroll
-            for (int m = 0; m < BB; ++m) {
-#pragma unroll
-                for (int c = 0; c < BB; ++c) {
-                    nl[c] = tf_fma(-Lr[m], rL(kLs)[m * BB + c], nl[c]);      // -L E_kL
-                    dl[c] = tf_fma(-Lr[m], rU(kLs)[m * BB + c], dl[c]);      // -L F_kL
-                    nu[c] = tf_fma(-Ur[m], rU(kRs)[m * BB + c], nu[c]);      // -U F_kR
-                    du[c] = tf_fma(-Ur[m], rL(kRs)[m * BB + c], du[c]);      // -U E_kR
-                }
-                yl = tf_fma(-Lr[m], sZ[kLs][m], yl);
-                yu = tf_fma(-Ur[m], sZ[kRs][m], yu);
-            }
-            if (vL) {
-#pragma unroll
-                for (int c = 0; c < BB; ++c) { rL(aL)[g * BB + c] = nl[c]; rD(aL)[g * BB + c] += dl[c]; }
-                sY[aL][g] += yl;
-            }
-            if (vR) {
-#pragma unroll
-                for (int c = 0; c < BB; ++c) { rU(aU)[g * BB + c] = nu[c]; rD(aU)[g * BB + c] += du[c]; }
-                sY[aU][g] += yu;
-            }
-        }
-        __syncthreads();
-    }
-
-    // ---- this chunk's share of the next level's rows
-    if (row_on && grp < 2) {
-        const int nn = grp == 0 ? ch.p : ch.pprev;
-        double* rec = a.Anext + ((int64_t)ch.e * a.Lnext.N + nn) * REC;
-        double* rr = a.rhsnext + ((int64_t)ch.e * a.Lnext.N + nn) * 2 * BB;
-        if (grp == 0) {
-#pragma unroll
-            for (int c = 0; c < BB; ++c) { rec[0 * B2 + g * BB + c] = rL(pe)[g * BB + c]; rec[1 * B2 + g * BB + c] = rD(pe)[g * BB + c]; }
-            if (with_rhs) rr[g] = sY[pe][g];
-        } else {
-#pragma unroll
-            for (int c = 0; c < BB; ++c) { rec[2 * B2 + g * BB + c] = rU(0)[g * BB + c]; rec[3 * B2 + g * BB + c] = rD(0)[g * BB + c]; }
-            if (with_rhs) rr[BB + g] = sY[0][g];
-        }
-    }
-    if (a.fold_top) {
-        // one chunk per system: what is left of rows 0 and pe couples the separator to
-        // itself only (TfTopArgs): invert their sum here, and solve for the first rhs
-        __syncthreads();
-        const bool on = grp == 0 && row_on;
-        double S[BB], INV[BB];
-#pragma unroll
-        for (int c = 0; c < BB; ++c)
-            S[c] = rL(pe)[gq * BB + c] + rD(pe)[gq * BB + c] + rU(0)[gq * BB + c] + rD(0)[gq * BB + c];
-        const int myk = tf_gj_coop<BB, G>(S, INV, on, g, sX + grp * 2 * G * (2 * BB + 1), ok);
-        if (on) {
-            const int nsys = L.Ptot;                 // P == 1
-#pragma unroll
-            for (int c = 0; c < BB; ++c) a.topAinv[(int64_t)(myk * BB + c) * nsys + ch.e] = INV[c];
-        }
-        if (with_rhs) {
-            // ... and the back-substitution of this level (tfk_cr_bwd_coop): E_k, F_k and z_k
-            // are still in LDS; sY takes the solution
-            double x = 0.0;
-            if (on) {
-#pragma unroll
-                for (int c = 0; c < BB; ++c) x = tf_fma(INV[c], sY[pe][c] + sY[0][c], x);
-            }
-            __syncthreads();
-            if (on) {
-                a.topx[(int64_t)ch.e * BB + myk] = x;
-                a.x[(ch.nbase + ch.node(pe)) * BB + myk] = x;
-                sY[pe][myk] = x;
-                sY[0][myk] = ch.has_prev ? x : 0.0;
-            }
-            __syncthreads();
-            int s = 1;
-            while (2 * s <= mI) s <<= 1;
-            for (; s >= 1; s >>= 1) {
-                const int nA = (mI / s + 1) / 2;
-                if (grp < nA && row_on) {
-                    const int k = s * (2 * grp + 1);
-                    const int kl = k - s, kr = k + s <= mI ? k + s : pe;
-                    double xk = sZ[k][g];
-#pragma unroll
-                    for (int m = 0; m < BB; ++m) {
-                        xk = tf_fma(-rL(k)[g * BB + m], sY[kl][m], xk);
-                        xk = tf_fma(-rU(k)[g * BB + m], sY[kr][m], xk);
-                    }
-                    sY[k][g] = xk;
-                    a.x[(ch.nbase + ch.node(k)) * BB + g] = xk;
-                }
-                __syncthreads();
-            }
-        }
-    }
-    if (!ok) *a.status = 1;
-}
+// The factorisation of these levels is tfk_cr_factor_v3 (tf_cr2_hip.h: a wavefront per node);
+// the round-1 version that stood here gave a node 8 lanes and took 155 us per step against 94
+// (profiles/README.md).  The solve kernels below read what the factorisation stores.
 
 // One block row (BB doubles, contiguous) of a stored record.  Records start at multiples of
 // 5*BB*BB doubles and a row at g*BB, so for even BB a row is 16-byte aligned and goes as
@@ -812,7 +598,7 @@ __device__ __forceinline__ void tfk_cr_fwd_coop(const TfLevelArgs& a) {
         }
     }
     if (a.fold_top) {
-        // last level: apply the inverse of the remaining block (tfk_cr_factor_coop) and run
+        // last level: apply the inverse of the remaining block (tfk_cr_factor_v3) and run
         // the back-substitution rounds of this level right away (tfk_cr_bwd_coop)
         double x = 0.0;
         if (row_on && grp == 0) {
@@ -1023,7 +809,7 @@ __device__ __forceinline__ void tfk_crs_factor(const TfLevelArgs& a) {
             }
         }
         __syncthreads();
-        // ---- phase B: the neighbours take the update (tasks as in tfk_cr_factor_coop)
+        // ---- phase B: the neighbours take the update (tasks as in tfk_cr_factor_v3)
         const int nB = mI / (2 * s);
         for (int t = tid; t <= nB; t += NT) {
             const bool ends = t == nB;

@@ -1,11 +1,11 @@
 // Cyclic-reduction factorisation of a reduced-level chunk with a WAVEFRONT per node (3 <= b <= 8).
 //
-// Same algorithm, task lists, stored quantities (a.crf, a.zt) and outputs as tfk_cr_factor_coop
-// (tf_coop_hip.h, the round-1 version: 8 lanes per node, kept as -DTF_CR_V2=0 for A/B runs) -- the
-// solve kernels tfk_cr_fwd / tfk_cr_bwd read what either writes -- but built around what these
-// levels cost: the latency of a round of dependent block inversions.  With 8 lanes per node every
-// pivot step is ~160 instructions of ONE wavefront (measured: 1300 cycles per pivot, 11 000 per
-// round, also with a DPP pivot search and a conflict-free LDS image: profiles/README.md).  Here:
+// The algorithm, task lists and stored quantities (a.crf, a.zt: what tfk_cr_fwd / tfk_cr_bwd read)
+// are described at the top of the cyclic-reduction section of tf_coop_hip.h.  The kernel is built
+// around what these levels cost: the latency of a round of dependent block inversions.  With 8
+// lanes per node (the round-1 version) every pivot step was ~160 instructions of ONE wavefront
+// (measured: 1300 cycles per pivot, 11 000 per round, also with a DPP pivot search and a
+// conflict-free LDS image: profiles/README.md).  Here:
 //   * Gauss-Jordan on the augmented row [L | D | U | y | I] of the node that goes: the lanes end
 //     with D^-1, E = D^-1 L, F = D^-1 U and z = D^-1 y, no product phase after the inversion;
 //   * the pivot row of a step is found with three DPP max steps inside an 8-lane group (key =

@@ -5,9 +5,6 @@
 #pragma once
 
 #include "tf_coop_hip.h"
-#ifndef TF_CR_V2
-#define TF_CR_V2 3        // 0: round-1 version (tf_coop_hip.h, 8 lanes per node), 3: tf_cr2_hip.h
-#endif
 #include "tf_cr2_hip.h"
 
 #define TF_GID ((int)(blockIdx.x * blockDim.x + threadIdx.x))
@@ -221,18 +218,15 @@ __global__ void __launch_bounds__(64) tfk_top_solve(TfTopArgs a) { tfk_top_body<
 // ---- cyclic-reduction levels (tf_coop_hip.h): 3 <= b <= 8 one wavefront per 16-node chunk
 //      (8 lanes per node); b <= 2 one thread per node, 256-node chunks
 #define TF_CR_BLOCK (TF_B2 <= 2 ? 256 : 64)
-// the factorisation of 3 <= b <= 8: 8 wavefronts per chunk (version 3), else one
-#define TF_CR_FACTOR_BLOCK (TF_B2 <= 2 ? 256 : (TF_CR_V2 == 3 ? 512 : 64))
+// the factorisation of 3 <= b <= 8: up to 8 wavefronts per chunk (tf_cr2_hip.h)
+#define TF_CR_FACTOR_BLOCK (TF_B2 <= 2 ? 256 : 512)
 #ifndef TF_CR_FACTOR_WAVES
 #define TF_CR_FACTOR_WAVES 4       // wavefronts per SIMD the register allocator makes room for
 #endif
 __global__ void __attribute__((amdgpu_waves_per_eu(TF_CR_FACTOR_WAVES))) __launch_bounds__(TF_CR_FACTOR_BLOCK)
 tfk_cr_factor(TfLevelArgs a) {
     if constexpr (TF_B2 <= 2) tfk_crs_factor<TF_B2>(a);
-    else if constexpr (TF_B2 <= 8) {
-        if constexpr (TF_CR_V2 == 3) tfk_cr_factor_v3<TF_B2>(a);
-        else tfk_cr_factor_coop<TF_B2>(a);
-    }
+    else if constexpr (TF_B2 <= 8) tfk_cr_factor_v3<TF_B2>(a);
 }
 __global__ void __launch_bounds__(TF_CR_BLOCK) tfk_cr_fwd(TfLevelArgs a) {
     if constexpr (TF_B2 <= 2) tfk_crs_fwd<TF_B2>(a);
