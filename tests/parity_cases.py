@@ -116,6 +116,68 @@ def check_linear_solve(name, backend, N, level_opts, c=0.01, tol=1e-9):
             assert np.abs(y - Jo @ rhs).max() <= 1e-12 * max(1.0, np.abs(Jo @ rhs).max())
 
 
+def check_respike(backend):
+    """Level-1 solves without the stored spike response (a.respike: second elimination of the
+    right-hand side with the separator above known, back-substitution with U alone -- the form
+    large multi-variable problems use) against the stored-E form and against SuperLU: plain solves
+    on several level plans, periodic and clamped, and steps whose first solve rides with the
+    factorisation, with a Dirichlet hook and with two members."""
+    import os
+    from triflow_amd.ensemble import Ensemble
+    rng = np.random.default_rng(11)
+
+    def with_env(value, fn):
+        os.environ["TRIFLOW_L1_RESPIKE"] = value
+        try:
+            return fn()
+        finally:
+            del os.environ["TRIFLOW_L1_RESPIKE"]
+
+    for name, N in (("M3_film", 1203), ("M5_stiff", 811), ("pair4", 403), ("six", 333)):
+        m, mo = device_model(name, backend), oracle_model(name)
+        for periodic in (True, False):
+            fd = corpus.synthetic_fields(name, N, seed=3, periodic=periodic, length=N * 5e-3)
+            pars = corpus.synthetic_pars(name, N, periodic)
+            Jo = mo.J(mo.fields_template(**fd), pars)
+            n = N * m._nvar
+            c = 0.01
+            rhs = rng.standard_normal(n)
+            xs = spla.spsolve(sps.identity(n, format="csc") - c * Jo, rhs)
+            for opts in (dict(refine=0), dict(refine=0, m1=8, m_upper=4), dict(refine=0, m1=5)):
+                xv = []
+                for flag in ("1", "0"):
+                    def run():
+                        solver = bound_solver(m, fd, pars, **opts)
+                        solver.eval(0, with_j=True)
+                        solver.factor(c)
+                        return solver.solve(rhs)[0]
+                    xv.append(with_env(flag, run))
+                e1 = np.abs(xv[0] - xs).max() / np.abs(xs).max()
+                e0 = np.abs(xv[1] - xs).max() / np.abs(xs).max()
+                # both are backward stable; neither may be much further from SuperLU than the other
+                assert e1 <= max(1e-9, 50 * e0), (name, periodic, opts, e1, e0)
+    for cfg, sch, hook, N, nsys in ((3, "ROS2", None, 3001, 2), (3, "RODASPR", None, 1501, 1),
+                                    (5, "BDF2", DEVICE_HOOKS["cfg5"], 2003, 1)):
+        name, fd, pars, dt, _ = corpus.config_inputs(cfg, N)
+        m = device_model(name, backend)
+        fields = {k: np.repeat(v[None, :], nsys, axis=0) * (1 + 0.01 * np.arange(nsys))[:, None]
+                  for k, v in fd.items() if k != "x"}
+        out = []
+        for flag in ("1", "0"):
+            def run():
+                ens = Ensemble(m, fd["x"], fields, pars, bool(pars["periodic"]), scheme=sch, hook=hook, nstate=2)
+                for _ in range(6):
+                    ens.step(dt)
+                ens.sync()
+                st = ens.state().copy()
+                ens.close()
+                return st
+            out.append(with_env(flag, run))
+        err = np.abs(out[0] - out[1]).max() / np.abs(out[1]).max()
+        print("respike vs stored E, config %d %s: %.1e" % (cfg, sch, err))
+        assert np.isfinite(out[0]).all() and err <= 1e-10, (cfg, sch, err)
+
+
 # ---------------------------------------------------------------- seam #2: schemes
 DEVICE_SCHEMES = {
     "Theta1": lambda m: schemes.Theta(m, theta=1),

@@ -104,6 +104,10 @@ def test_row_monitor(backend):
     pc.check_row_monitor(backend)
 
 
+def test_respike(backend):
+    pc.check_respike(backend)
+
+
 def test_fused_stage_rhs(backend):
     pc.check_fused_stage_rhs(backend)
 

@@ -385,6 +385,10 @@ def test_row_monitor():
     pc.check_row_monitor(HIP)
 
 
+def test_respike():
+    pc.check_respike(HIP)
+
+
 def test_fused_stage_rhs():
     pc.check_fused_stage_rhs(HIP)
 

@@ -205,6 +205,10 @@ struct TfLevelArgs {
     // last cyclic-reduction level (one chunk per system): it also inverts / applies the
     // single block that is left (what tfk_top_* do otherwise)
     int fold_top;
+    // level 1 only: the spike response E of the down walk is not stored; once the separators are
+    // solved, tfk_l1_fwd2 eliminates the right-hand side again with the separator above known, and
+    // the back-substitution uses U alone (tfk_l1_backsub_u).  Chosen per solver (TF_RESPIKE_*).
+    int respike;
     double* topAinv;               // [b][b] planes over systems (TfTopArgs::Ainv)
     double* topx;                  // [sys][b]
     // diagnostic builds (-DTF_STAMPS): one workgroup writes s_memtime stamps here (else NULL)
@@ -220,6 +224,14 @@ struct TfTopArgs {                 // final 1-node system per ensemble member
     int* status;
     int aos;                       // 1: A [sys][4][b][b], rhs [sys][2][b], x [sys][b] (cyclic-reduction levels below)
 };
+
+// Level-1 spike response stored (E: mp*nvar^2 doubles per node, written by the factorisation and
+// read by every back-substitution) or replaced by a second elimination of the right-hand side:
+// the second form moves fewer bytes but costs a walk per solve.  It wins where E is big and the
+// problem fills the GPU (config 3 x 8 members +9 %, config 5 +10 %, config 3 +1.3 %) and loses
+// on scalar models (config 2 -12 %) and small grids (-5 % at 2e5 nodes): profiles/r02_ab_runs.txt.
+#define TF_RESPIKE_MODEL(mp, nvar) ((mp) * (nvar) * (nvar) >= 8)
+#define TF_RESPIKE_MIN_NODES 750000
 
 // nodes per thread of tfk_sweep_f_stage_rhs (the other sweeps: TF_SEG of the code object, 4 or 8).
 // Two register windows per variable make its ghost rows twice as expensive: 8 nodes per thread
@@ -239,7 +251,7 @@ enum TfKernel {
     TFK_BT_LU, TFK_BT_SPIKE, TFK_BT_RHS, TFK_BT_ASM_MAT, TFK_BT_ASM_RHS, TFK_BT_BACKSUB,
     TFK_TOP_FACTOR, TFK_TOP_SOLVE, TFK_BERR, TFK_DIFFNORM, TFK_L1_FACTOR_RHS, TFK_SWEEP_F_STAGE,
     TFK_CR_FACTOR, TFK_CR_FWD, TFK_CR_BWD, TFK_POKE, TFK_SWEEP_FJ_THETA, TFK_SWEEP_FJ_BDF2, TFK_SPMV_MON, TFK_GATHER,
-    TFK_SWEEP_F_STAGE_RHS, TFK_COUNT
+    TFK_SWEEP_F_STAGE_RHS, TFK_L1_FWD2, TFK_L1_BACKSUB_U, TFK_COUNT
 };
 #define TF_KERNEL_NAMES { \
     "tfk_sweep_f", "tfk_sweep_fj", "tfk_spmv", "tfk_vec", "tfk_vec_maxabs", "tfk_perm", "tfk_dirichlet", \
@@ -247,4 +259,4 @@ enum TfKernel {
     "tfk_bt_lu", "tfk_bt_spike", "tfk_bt_rhs", "tfk_bt_asm_mat", "tfk_bt_asm_rhs", "tfk_bt_backsub", \
     "tfk_top_factor", "tfk_top_solve", "tfk_berr", "tfk_diffnorm", "tfk_l1_factor_rhs", "tfk_sweep_f_stage", \
     "tfk_cr_factor", "tfk_cr_fwd", "tfk_cr_bwd", "tfk_poke", "tfk_sweep_fj_theta", "tfk_sweep_fj_bdf2", \
-    "tfk_spmv_mon", "tfk_gather", "tfk_sweep_f_stage_rhs" }
+    "tfk_spmv_mon", "tfk_gather", "tfk_sweep_f_stage_rhs", "tfk_l1_fwd2", "tfk_l1_backsub_u" }

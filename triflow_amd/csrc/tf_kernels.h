@@ -793,9 +793,10 @@ struct TfRowsBT {
 // behind the walk as MP*B extra right-hand sides and emit the V/W tips.
 // STORE (down walk only): keep the normalised pivot rows Ut (and Et when SPIKE)
 // for the back-substitution; the down solve walk stores yt.
-template <class Rows, int DIR, bool SPIKE, bool STORE_U, bool STORE_Y>
+template <class Rows, int DIR, bool SPIKE, bool STORE_U, bool STORE_Y, bool KNOWN = false>
 TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
     constexpr int B = Rows::B, MP = Rows::MP, W = 2 * MP + 1;
+    static_assert(!KNOWN || (DIR > 0 && !SPIKE && !STORE_U), "the re-elimination walks down, one right-hand side");
     constexpr bool PIV = Rows::PIVOT;             // row exchanges inside the window (B == 1)
     constexpr int UW = PIV ? 2 * MP : MP;         // blocks right of the pivot kept in U
     static_assert(!PIV || B == 1, "row exchanges are written for scalar blocks");
@@ -815,6 +816,22 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
     double Uh[MP][UW][B][B], yh[MP][B];
     double Eh[SPIKE ? MP : 1][SPIKE ? MP : 1][B][B];
     bool ok = true;
+    // KNOWN: the separator behind (above) is solved; its values move to the right-hand side of
+    // the first MP rows, the only ones that couple to it
+    double sa[KNOWN ? MP : 1][B];
+    if (KNOWN) {
+        const int e = pg / L.P, p = pg - e * L.P;
+        const bool has_above = L.periodic || p > 0;
+        const int pa = p > 0 ? p - 1 : L.P - 1;
+        int p2, i2;
+        tf_locate(a.Lnext, pa, p2, i2);
+        const int64_t s2a = tf_idx(a.Lnext, e * a.Lnext.P + p2, i2);
+#pragma unroll
+        for (int t = 0; t < MP; ++t)
+#pragma unroll
+            for (int r = 0; r < B; ++r)
+                sa[KNOWN ? t : 0][r] = has_above ? a.xnext[tf_next_x(a, e, pa, s2a, t * B + r, MP * B)] : 0.0;
+    }
 
     // Rows enter the window in local order 0, 1, 2, ...; their values are requested
     // two rows ahead of their use so that the walk does not wait on memory per node.
@@ -841,6 +858,8 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
             double row[W][B][B];
             rows.decode(node(jl), pre.raw, row);
 #pragma unroll
+            for (int r = 0; r < B; ++r) y[q][r] = pre.y[r];
+#pragma unroll
             for (int d = -MP; d <= MP; ++d) {
                 const int c = q + d;               // local column relative to the pivot
                 const int dd = DIR > 0 ? d : -d;   // natural offset
@@ -850,10 +869,11 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
                     // column jl + d < 0: separator behind, local position MP + (jl + d)
                     const int t = MP + jl + d;
                     if (t >= 0 && t < MP) tf_blk_copy<B>(Es[SPIKE ? q : 0][SPIKE ? t : 0], row[dd + MP]);
+                } else if (KNOWN) {
+                    const int t = MP + jl + d;
+                    if (t >= 0 && t < MP) tf_mv_sub<B>(y[q], row[dd + MP], sa[KNOWN ? t : 0]);
                 }
             }
-#pragma unroll
-            for (int r = 0; r < B; ++r) y[q][r] = pre.y[r];
         }
     };
     // columns c < 0 only occur for the first MP local rows (jl + d < 0); there the
@@ -925,6 +945,8 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
                 for (int t = 0; t < MP; ++t) tf_mm_sub<B>(Es[q][t], R[q][0], En[t]);
             }
         }
+        // (a.respike: E and y of the first elimination are not kept, see tfk_l1_fwd2)
+        const bool keep = KNOWN || !a.respike;
         if (STORE_U || STORE_Y) {
             const int64_t s = tf_idx(L, pg, node(j));
             if (STORE_U) {
@@ -935,11 +957,11 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
 #pragma unroll
                         for (int k = 0; k < B; ++k) {
                             a.Ut[(int64_t)((c * B + r) * B + k) * L.plane + s] = Un[c][r][k];
-                            if (SPIKE && c < MP)
+                            if (SPIKE && keep && c < MP)
                                 a.Et[(int64_t)((c * B + r) * B + k) * L.plane + s] = En[SPIKE && c < MP ? c : 0][r][k];
                         }
             }
-            if (STORE_Y) {
+            if (STORE_Y && keep) {
 #pragma unroll
                 for (int r = 0; r < B; ++r) a.yt[(int64_t)r * L.plane + s] = yn[r];
             }
@@ -969,6 +991,11 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
             }
         }
     };
+    if (KNOWN) {
+        for (int j = 0; j < mI; ++j) pivot(j, TfInt<-1>());
+        if (!ok) *a.status = 1;
+        return;
+    }
     for (int j = 0; j < mI - MP; ++j) pivot(j, TfInt<-1>());
     pivot(mI - MP, TfInt<0>());
     if (MP > 1) pivot(mI - MP + 1, TfInt<(MP > 1 ? 1 : 0)>());
@@ -1280,7 +1307,7 @@ TF_DEVICE void tfk_asm_body(const TfLevelArgs& a, int pg, double* stage = nullpt
 }
 
 // ---- back-substitution of one chunk (separators known) ----------------------
-template <class Rows>
+template <class Rows, bool WITH_E = true>
 TF_DEVICE void tfk_backsub_body(const TfLevelArgs& a, int pg) {
     constexpr int B = Rows::B, MP = Rows::MP;
     constexpr int UW = Rows::PIVOT ? 2 * MP : MP;  // see tfk_chunk_body
@@ -1318,7 +1345,7 @@ TF_DEVICE void tfk_backsub_body(const TfLevelArgs& a, int pg) {
     }
     // the factors of node j-1 are requested before node j is processed, so one
     // HBM latency is paid per chunk, not per node
-    struct Node { double y[B]; double U[UW][B][B]; double E[MP][B][B]; };
+    struct Node { double y[B]; double U[UW][B][B]; double E[WITH_E ? MP : 1][B][B]; };
     auto load = [&](int j, Node& n) {
         const int64_t s = tf_idx(L, pg, j);
 #pragma unroll
@@ -1330,7 +1357,7 @@ TF_DEVICE void tfk_backsub_body(const TfLevelArgs& a, int pg) {
 #pragma unroll
                 for (int k = 0; k < B; ++k) {
                     n.U[c][r][k] = a.Ut[(int64_t)((c * B + r) * B + k) * L.plane + s];
-                    if (c < MP) n.E[c < MP ? c : 0][r][k] = a.Et[(int64_t)((c * B + r) * B + k) * L.plane + s];
+                    if (WITH_E && c < MP) n.E[WITH_E && c < MP ? c : 0][r][k] = a.Et[(int64_t)((c * B + r) * B + k) * L.plane + s];
                 }
     };
     // TF_BACKSUB_DEPTH nodes of factors in flight per thread: the walk is a chain of loads
@@ -1353,8 +1380,10 @@ TF_DEVICE void tfk_backsub_body(const TfLevelArgs& a, int pg) {
             for (int r = 0; r < B; ++r) x[r] = cur.y[r];
 #pragma unroll
             for (int c = 0; c < UW; ++c) tf_mv_sub<B>(x, cur.U[c], xn[c]);
+            if (WITH_E) {
 #pragma unroll
-            for (int c = 0; c < MP; ++c) tf_mv_sub<B>(x, cur.E[c], sa[c]);
+                for (int c = 0; c < MP; ++c) tf_mv_sub<B>(x, cur.E[WITH_E ? c : 0], sa[c]);
+            }
 #pragma unroll
             for (int c = UW - 1; c > 0; --c)
 #pragma unroll

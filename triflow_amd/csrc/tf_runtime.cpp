@@ -394,6 +394,7 @@ struct tf_solver {
     // combination of the same k_j loads.  When the monitor is due, the two-kernel form runs
     // (tfk_sweep_f_stage, tfk_spmv_mon): same operations, same bits.
     bool fuse_stage = true;
+    bool l1_respike = false;       // level-1 spike response not stored (tf_args.h, TF_RESPIKE_*)
     void stage_rhs(const double* Uin, int nterms, const double* const* ks, const double* ac,
                    const double* gc, double dt, double* y, const double* monitor_rhs) {
         if (!fuse_stage || monitor_due(monitor_rhs, nterms, gc)) {
@@ -456,6 +457,7 @@ struct tf_solver {
         a.status = status;
         a.next_aos = next_aos(l) ? 1 : 0; a.crf = lv.crf.p; a.zt = lv.zt.p;
         a.fold_top = fold_top() && l + 1 == levels.size() ? 1 : 0;
+        a.respike = l == 0 && l1_respike ? 1 : 0;
         a.topAinv = topAinv.p; a.topx = top.x.p;
         a.stamps = stamp_buf.n ? (unsigned long long*)stamp_buf.p + 64 * l : nullptr;
         return a;
@@ -515,7 +517,10 @@ struct tf_solver {
     void backsub_chain(const double* rhs1, double* x1, bool skip_last) {
         for (size_t l = levels.size() - (skip_last ? 1 : 0); l-- > 0;) {
             TfLevelArgs a = level_args(l, rhs1, x1);
-            if (l == 0) launch(TFK_L1_BACKSUB, cdiv(a.L.Ptot, 64), 1, 64, &a, sizeof(a));
+            if (l == 0) {
+                if (l1_respike) launch(TFK_L1_FWD2, cdiv(a.L.Ptot, 64), 1, 64, &a, sizeof(a));
+                launch(l1_respike ? TFK_L1_BACKSUB_U : TFK_L1_BACKSUB, cdiv(a.L.Ptot, 64), 1, 64, &a, sizeof(a));
+            }
             else if (levels[l]->cr) launch(TFK_CR_BWD, (unsigned)a.L.Ptot, 1, cr_block(), &a, sizeof(a));
             else launch(TFK_BT_BACKSUB, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
         }
@@ -698,6 +703,9 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
     s->graphs_on = tfb::graphs_supported() && (int64_t)N * nsys <= 50000;
     if (const char* v = getenv("TRIFLOW_GRAPHS")) s->graphs_on = tfb::graphs_supported() && atoi(v) != 0;
     if (const char* v = getenv("TRIFLOW_FUSE_STAGE")) s->fuse_stage = atoi(v) != 0;      // A/B runs
+    s->l1_respike = TF_RESPIKE_MODEL(sp.mp, sp.nvar) && (int64_t)N * nsys >= TF_RESPIKE_MIN_NODES;
+    if (const char* v = getenv("TRIFLOW_L1_RESPIKE"))                                   // A/B runs, tests
+        s->l1_respike = TF_RESPIKE_MODEL(sp.mp, sp.nvar) && atoi(v) != 0;
 
     // ---- level plan: chunk levels until a single chunk is left, then the top block.
     // Reduced levels: walks over chunks of m_upper nodes, or -- where the back end has
@@ -785,7 +793,8 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
         // level 1 of a scalar model exchanges rows inside the band: U is 2*MP wide
         const int UW = (l == 0 && B == 1) ? 2 * MP : MP;
         lv.Ut.alloc((size_t)UW * B * B * pl, tot);
-        lv.Et.alloc((size_t)MP * B * B * pl, tot);
+        if (l == 0 && s->l1_respike) lv.Et.alloc(1, tot);
+        else lv.Et.alloc((size_t)MP * B * B * pl, tot);
         lv.yt.alloc((size_t)B * pl, tot);
         const size_t tipsz = (size_t)(MP * B + 2 * MP * MP * B * B) * lv.L.Ptot;
         lv.tips_dn.alloc(tipsz, tot);
