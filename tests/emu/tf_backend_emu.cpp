@@ -105,12 +105,15 @@ void launch(Module*, int kernel, unsigned gx, unsigned gy, unsigned block,
 #define TF_EMU_CHUNK(ID, ROWS, SP, SU, SY)                                              \
     case ID: { const auto& a = *(const TfLevelArgs*)args;                               \
         for (int64_t t = 0; t < nthreads; ++t) tfk_chunk_body<ROWS, +1, SP, SU, SY>(a, (int)t); \
-        for (int64_t t = 0; t < nthreads; ++t) tfk_chunk_body<ROWS, -1, SP, false, false>(a, (int)t); } break;
+        for (int64_t t = 0; t < nthreads; ++t) tfk_chunk_body<ROWS, -1, SP, SU && TF_RESPIKE_MODEL(TF_MP, TF_NVAR), false>(a, (int)t); } break;
     TF_EMU_CHUNK(TFK_L1_FACTOR, TfRowsL1, true, true, false)
     TF_EMU_CHUNK(TFK_L1_SOLVE, TfRowsL1, false, false, true)
     TF_EMU_CHUNK(TFK_L1_FACTOR_RHS, TfRowsL1, true, true, true)
     case TFK_L1_FWD2: { const auto& a = *(const TfLevelArgs*)args;
-        for (int64_t t = 0; t < nthreads; ++t) tfk_chunk_body<TfRowsL1, +1, false, false, true, true>(a, (int)t); } break;
+        if constexpr (TF_RESPIKE_MODEL(TF_MP, TF_NVAR)) {
+            for (int64_t t = 0; t < nthreads; ++t) tfk_chunk_body<TfRowsL1, +1, false, false, true, true>(a, (int)t);
+            for (int64_t t = 0; t < nthreads; ++t) tfk_chunk_body<TfRowsL1, -1, false, false, true, true>(a, (int)t);
+        } } break;
     case TFK_BT_LU: { const auto& a = *(const TfLevelArgs*)args;
         for (unsigned y = 0; y < gy; ++y) for (int64_t t = 0; t < nthreads; ++t)
             tfk_bt_lu_body<TF_B2>(a, (int)t, y == 0 ? +1 : -1); } break;
@@ -126,7 +129,11 @@ void launch(Module*, int kernel, unsigned gx, unsigned gy, unsigned block,
     TF_EMU_LEVEL(TFK_L1_ASM_MAT, (tfk_asm_body<TfRowsL1, true>))
     TF_EMU_LEVEL(TFK_L1_ASM_RHS, (tfk_asm_body<TfRowsL1, false>))
     TF_EMU_LEVEL(TFK_L1_BACKSUB, (tfk_backsub_body<TfRowsL1, true>))
-    TF_EMU_LEVEL(TFK_L1_BACKSUB_U, (tfk_backsub_body<TfRowsL1, false>))
+    case TFK_L1_BACKSUB_U: { const auto& a = *(const TfLevelArgs*)args;
+        if constexpr (TF_RESPIKE_MODEL(TF_MP, TF_NVAR)) {
+            for (int dir = 0; dir < 2; ++dir)
+                for (int64_t t = 0; t < nthreads; ++t) tfk_backsub_twist_body<TfRowsL1>(a, (int)t, dir);
+        } } break;
     TF_EMU_LEVEL(TFK_BT_ASM_MAT, (tfk_asm_body<TfRowsUp, true>))
     TF_EMU_LEVEL(TFK_BT_ASM_RHS, (tfk_asm_body<TfRowsUp, false>))
     TF_EMU_LEVEL(TFK_BT_BACKSUB, (tfk_backsub_body<TfRowsUp>))

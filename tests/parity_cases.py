@@ -143,7 +143,9 @@ def check_respike(backend):
             c = 0.01
             rhs = rng.standard_normal(n)
             xs = spla.spsolve(sps.identity(n, format="csc") - c * Jo, rhs)
-            for opts in (dict(refine=0), dict(refine=0, m1=8, m_upper=4), dict(refine=0, m1=5)):
+            # chunk lengths on both sides of the twisted form's limits (tf_twist_h: 4 mp interior nodes)
+            for opts in (dict(refine=0), dict(refine=0, m1=8, m_upper=4), dict(refine=0, m1=5),
+                         dict(refine=0, m1=32), dict(refine=0, m1=13, m_upper=5), dict(refine=0, m1=10)):
                 xv = []
                 for flag in ("1", "0"):
                     def run():
@@ -165,7 +167,8 @@ def check_respike(backend):
         out = []
         for flag in ("1", "0"):
             def run():
-                ens = Ensemble(m, fd["x"], fields, pars, bool(pars["periodic"]), scheme=sch, hook=hook, nstate=2)
+                ens = Ensemble(m, fd["x"], fields, pars, bool(pars["periodic"]), scheme=sch, hook=hook, nstate=2,
+                               m1=32)
                 for _ in range(6):
                     ens.step(dt)
                 ens.sync()

@@ -141,26 +141,30 @@ __global__ void __launch_bounds__(64) tfk_poke(TfPokeArgs a) {
 // grid.y: 0 = walk down, 1 = walk up (wave-uniform)
 __global__ void __launch_bounds__(64) tfk_l1_factor(TfLevelArgs a) {
     if (blockIdx.y == 0) tfk_chunk_body<TfRowsL1, +1, true, true, false>(a, TF_GID);
-    else tfk_chunk_body<TfRowsL1, -1, true, false, false>(a, TF_GID);
+    else tfk_chunk_body<TfRowsL1, -1, true, TF_RESPIKE_MODEL(TF_MP, TF_NVAR), false>(a, TF_GID);
 }
 // factorisation that also eliminates a first right-hand side (the first solve of a
 // time step rides along: no second walk over J for it)
 __global__ void __launch_bounds__(64) tfk_l1_factor_rhs(TfLevelArgs a) {
     if (blockIdx.y == 0) tfk_chunk_body<TfRowsL1, +1, true, true, true>(a, TF_GID);
-    else tfk_chunk_body<TfRowsL1, -1, true, false, false>(a, TF_GID);
+    else tfk_chunk_body<TfRowsL1, -1, true, TF_RESPIKE_MODEL(TF_MP, TF_NVAR), false>(a, TF_GID);
 }
 __global__ void __launch_bounds__(64) tfk_l1_solve(TfLevelArgs a) {
     if (blockIdx.y == 0) tfk_chunk_body<TfRowsL1, +1, false, false, true>(a, TF_GID);
     else tfk_chunk_body<TfRowsL1, -1, false, false, false>(a, TF_GID);
 }
 // Second elimination of a right-hand side, once the separators are solved: the values of the
-// separator above a chunk go to the right-hand side of its first rows, the elimination is
+// separator behind a walk go to the right-hand side of its first rows, the elimination is
 // recomputed from J (as in tfk_l1_solve) and leaves y for the back-substitution with U alone.
 // Replaces the stored spike response E (mp nvar^2 doubles per node written by the factorisation
-// and read by every back-substitution) by the Jacobian planes read once more; compiled for the
-// models it can pay for (TF_RESPIKE_MODEL), chosen per solver by size (tf_args.h).
+// and read by every back-substitution) by the Jacobian planes read once more.  grid.y: 0 = down
+// half, 1 = up half of every chunk (tf_twist_h).  Compiled for the models it can pay for
+// (TF_RESPIKE_MODEL), chosen per solver by size (tf_args.h).
 __global__ void __launch_bounds__(64) tfk_l1_fwd2(TfLevelArgs a) {
-    if constexpr (TF_RESPIKE_MODEL(TF_MP, TF_NVAR)) tfk_chunk_body<TfRowsL1, +1, false, false, true, true>(a, TF_GID);
+    if constexpr (TF_RESPIKE_MODEL(TF_MP, TF_NVAR)) {
+        if (blockIdx.y == 0) tfk_chunk_body<TfRowsL1, +1, false, false, true, true>(a, TF_GID);
+        else tfk_chunk_body<TfRowsL1, -1, false, false, true, true>(a, TF_GID);
+    }
 }
 // The next level's rows.  When that level keeps records per node (cyclic reduction), the 64
 // rows of a workgroup are collected in LDS and leave as whole records: coalesced stores of
@@ -188,7 +192,7 @@ __global__ void __launch_bounds__(64) tfk_l1_asm_mat(TfLevelArgs a) {
 __global__ void __launch_bounds__(64) tfk_l1_asm_rhs(TfLevelArgs a) { tfk_asm_body<TfRowsL1, false>(a, TF_GID); }
 __global__ void __launch_bounds__(64) tfk_l1_backsub(TfLevelArgs a) { tfk_backsub_body<TfRowsL1, true>(a, TF_GID); }
 __global__ void __launch_bounds__(64) tfk_l1_backsub_u(TfLevelArgs a) {
-    if constexpr (TF_RESPIKE_MODEL(TF_MP, TF_NVAR)) tfk_backsub_body<TfRowsL1, false>(a, TF_GID);
+    if constexpr (TF_RESPIKE_MODEL(TF_MP, TF_NVAR)) tfk_backsub_twist_body<TfRowsL1>(a, TF_GID, (int)blockIdx.y);
 }
 
 // ---- banded solver, levels >= 2 (explicit block-tridiagonal rows) -----------

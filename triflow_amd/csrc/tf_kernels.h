@@ -787,16 +787,37 @@ struct TfRowsBT {
 #define TF_BACKSUB_DEPTH 3
 #endif
 
+// Twisted re-elimination (a.respike).  With the separators known, the interior of a chunk is a
+// banded system with known values on both sides, so it need not be swept end to end: the down
+// walk owns its first h nodes, the up walk the other mI - h, both eliminate towards the middle at
+// the same time (tfk_l1_fwd2, two threads per chunk), the 2*MP nodes where they meet are solved
+// as one small system, and the two halves are back-substituted outwards (tfk_l1_backsub_u, two
+// threads per chunk).  Half the latency per walk and twice the wavefronts -- 31 250 chunks are
+// only 489 wavefronts for 1024 SIMDs.  The factorisation stores the normalised pivot rows U of
+// the down walk for the first h nodes and those of the up walk for the others: the same bytes.
+// Chunks too short for two halves (and blocks too big for the middle system in registers) keep
+// h = mI: the up half is empty and everything reduces to the one-sided form.
+#ifndef TF_TWIST
+#define TF_TWIST 1
+#endif
+template <int B, int MP>
+TF_DEVICE int tf_twist_h(int mI) {
+    return (TF_TWIST && MP * B <= 6 && mI >= 4 * MP) ? (mI + 1) / 2 : mI;
+}
+
 // ---- interior elimination of one chunk in one direction --------------------
 // DIR = +1 walks down (local j <-> node j), DIR = -1 walks up (local j <-> node
 // mI-1-j, offsets mirrored).  SPIKE: also carry the coupling to the separator
 // behind the walk as MP*B extra right-hand sides and emit the V/W tips.
-// STORE (down walk only): keep the normalised pivot rows Ut (and Et when SPIKE)
-// for the back-substitution; the down solve walk stores yt.
+// STORE_U: keep the normalised pivot rows Ut (and Et when SPIKE and the spike response is
+// stored) for the back-substitution -- the down walk all of them, or, with a.respike, each walk
+// those of its half (tf_twist_h); STORE_Y: the down solve walk stores yt.
+// KNOWN (tfk_l1_fwd2): the separator behind the walk is solved; the walk eliminates its half
+// of the chunk with those values on the right-hand side and stores yt.
 template <class Rows, int DIR, bool SPIKE, bool STORE_U, bool STORE_Y, bool KNOWN = false>
 TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
     constexpr int B = Rows::B, MP = Rows::MP, W = 2 * MP + 1;
-    static_assert(!KNOWN || (DIR > 0 && !SPIKE && !STORE_U), "the re-elimination walks down, one right-hand side");
+    static_assert(!KNOWN || (!SPIKE && !STORE_U), "the re-elimination takes one right-hand side");
     constexpr bool PIV = Rows::PIVOT;             // row exchanges inside the window (B == 1)
     constexpr int UW = PIV ? 2 * MP : MP;         // blocks right of the pivot kept in U
     static_assert(!PIV || B == 1, "row exchanges are written for scalar blocks");
@@ -816,21 +837,25 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
     double Uh[MP][UW][B][B], yh[MP][B];
     double Eh[SPIKE ? MP : 1][SPIKE ? MP : 1][B][B];
     bool ok = true;
-    // KNOWN: the separator behind (above) is solved; its values move to the right-hand side of
-    // the first MP rows, the only ones that couple to it
+    // KNOWN: the separator behind the walk is solved; its values move to the right-hand side of
+    // the first MP rows, the only ones that couple to it (local order: the node next to the
+    // interior is the last one)
     double sa[KNOWN ? MP : 1][B];
+    const int hdn = tf_twist_h<B, MP>(mI);           // nodes of the down half (a.respike)
     if (KNOWN) {
         const int e = pg / L.P, p = pg - e * L.P;
-        const bool has_above = L.periodic || p > 0;
-        const int pa = p > 0 ? p - 1 : L.P - 1;
+        const bool has_sep = DIR < 0 || L.periodic || p > 0;
+        const int ps = DIR < 0 ? p : (p > 0 ? p - 1 : L.P - 1);
         int p2, i2;
-        tf_locate(a.Lnext, pa, p2, i2);
+        tf_locate(a.Lnext, ps, p2, i2);
         const int64_t s2a = tf_idx(a.Lnext, e * a.Lnext.P + p2, i2);
 #pragma unroll
-        for (int t = 0; t < MP; ++t)
+        for (int t = 0; t < MP; ++t) {
+            const int tn = DIR > 0 ? t : MP - 1 - t;
 #pragma unroll
             for (int r = 0; r < B; ++r)
-                sa[KNOWN ? t : 0][r] = has_above ? a.xnext[tf_next_x(a, e, pa, s2a, t * B + r, MP * B)] : 0.0;
+                sa[KNOWN ? t : 0][r] = has_sep ? a.xnext[tf_next_x(a, e, ps, s2a, tn * B + r, MP * B)] : 0.0;
+        }
     }
 
     // Rows enter the window in local order 0, 1, 2, ...; their values are requested
@@ -945,11 +970,13 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
                 for (int t = 0; t < MP; ++t) tf_mm_sub<B>(Es[q][t], R[q][0], En[t]);
             }
         }
-        // (a.respike: E and y of the first elimination are not kept, see tfk_l1_fwd2)
+        // (a.respike: E and y of the first elimination are not kept, and each walk keeps the U of
+        // its half, see tfk_l1_fwd2)
         const bool keep = KNOWN || !a.respike;
+        const bool keep_u = a.respike ? (DIR > 0 ? j < hdn : j < mI - hdn) : DIR > 0;
         if (STORE_U || STORE_Y) {
             const int64_t s = tf_idx(L, pg, node(j));
-            if (STORE_U) {
+            if (STORE_U && keep_u) {
 #pragma unroll
                 for (int c = 0; c < UW; ++c)
 #pragma unroll
@@ -992,7 +1019,8 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
         }
     };
     if (KNOWN) {
-        for (int j = 0; j < mI; ++j) pivot(j, TfInt<-1>());
+        const int np = DIR > 0 ? hdn : mI - hdn;     // this walk's half
+        for (int j = 0; j < np; ++j) pivot(j, TfInt<-1>());
         if (!ok) *a.status = 1;
         return;
     }
@@ -1386,6 +1414,213 @@ TF_DEVICE void tfk_backsub_body(const TfLevelArgs& a, int pg) {
             }
 #pragma unroll
             for (int c = UW - 1; c > 0; --c)
+#pragma unroll
+                for (int r = 0; r < B; ++r) xn[c][r] = xn[c - 1][r];
+#pragma unroll
+            for (int r = 0; r < B; ++r) { xn[0][r] = x[r]; a.x[(int64_t)r * L.plane + s] = x[r]; }
+            if (j - D >= 0) load(j - D, ring[d]);
+        }
+    }
+}
+
+// n x n system with partial pivoting, everything in registers (n <= 6: the middle of a chunk)
+template <int n>
+TF_DEVICE bool tf_dense_solve(double (&S)[n][n], double (&g)[n]) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+#pragma unroll
+        for (int r = k + 1; r < n; ++r) {            // largest |entry| of column k to row k
+            const bool sw = tf_abs(S[r][k]) > tf_abs(S[k][k]);
+#pragma unroll
+            for (int c = k; c < n; ++c) { const double u = S[k][c], v = S[r][c]; S[k][c] = sw ? v : u; S[r][c] = sw ? u : v; }
+            { const double u = g[k], v = g[r]; g[k] = sw ? v : u; g[r] = sw ? u : v; }
+        }
+        const double piv = S[k][k];
+        ok = ok && (piv != 0.0) && (piv == piv);
+        const double rp = 1.0 / piv;
+#pragma unroll
+        for (int c = k + 1; c < n; ++c) S[k][c] = S[k][c] * rp;
+        g[k] = g[k] * rp;
+#pragma unroll
+        for (int r = k + 1; r < n; ++r) {
+            const double f = S[r][k];
+#pragma unroll
+            for (int c = k + 1; c < n; ++c) S[r][c] = tf_fma(-f, S[k][c], S[r][c]);
+            g[r] = tf_fma(-f, g[k], g[r]);
+        }
+    }
+#pragma unroll
+    for (int k = n - 2; k >= 0; --k)
+#pragma unroll
+        for (int c = k + 1; c < n; ++c) g[k] = tf_fma(-S[k][c], g[c], g[k]);
+    return ok;
+}
+
+// Back-substitution of the re-elimination form (a.respike; tf_twist_h): dir 0 takes the down
+// half of the chunk, dir 1 the up half.  Both first solve the 2*MP nodes where the halves meet
+//   down rows r = h-MP..h-1:  x_r + sum_c U_r[c]  x_{r+1+c} = y_r
+//   up rows   r = h..h+MP-1:  x_r + sum_c U'_r[c] x_{r-1-c} = y'_r
+// (a = the down unknowns, b = the up unknowns: T1 a + C1 b = g1, C2 a + T2 b = g2 with unit
+// triangular T1, T2; b from the Schur complement T2 - C2 T1^-1 C1, pivoted; the same arithmetic
+// in both threads) and then stream their own half outwards like tfk_backsub_body.
+template <class Rows>
+TF_DEVICE void tfk_backsub_twist_body(const TfLevelArgs& a, int pg, int dir) {
+    constexpr int B = Rows::B, MP = Rows::MP, NB = MP * B;
+    static_assert(!Rows::PIVOT, "the re-elimination form is for block sizes that do not exchange rows");
+    const TfLayout& L = a.L;
+    if (pg >= L.Ptot) return;
+    const int e = pg / L.P, p = pg - e * L.P;
+    const int len = tf_len(L, p), mI = len - MP;
+    const int h = tf_twist_h<B, MP>(mI), hu = mI - h;
+    if (dir == 1 && hu == 0) return;
+    double xn[MP][B];                              // the MP solved nodes ahead of the walk, nearest first
+    // local index (walking direction) of the first node of the streamed part: one-sided, ahead of
+    // the last pivot lies the separator; twisted, the MP nodes next to the middle are solved there
+    const int jstart = hu == 0 ? mI - 1 : (dir == 0 ? h - MP - 1 : hu - MP - 1);
+    auto nat = [&](int j) { return dir == 0 ? j : mI - 1 - j; };
+    auto ldU = [&](int node_nat, double (&U)[MP][B][B], double (&y)[B]) {
+        const int64_t s = tf_idx(L, pg, node_nat);
+#pragma unroll
+        for (int r = 0; r < B; ++r) y[r] = a.yt[(int64_t)r * L.plane + s];
+#pragma unroll
+        for (int c = 0; c < MP; ++c)
+#pragma unroll
+            for (int r = 0; r < B; ++r)
+#pragma unroll
+                for (int k = 0; k < B; ++k) U[c][r][k] = a.Ut[(int64_t)((c * B + r) * B + k) * L.plane + s];
+    };
+    if (hu == 0 || dir == 0) {
+        // the chunk's own separator: solved by the next level
+        int p2, i2;
+        tf_locate(a.Lnext, p, p2, i2);
+        const int64_t s2 = tf_idx(a.Lnext, e * a.Lnext.P + p2, i2);
+#pragma unroll
+        for (int t = 0; t < MP; ++t) {
+            const int64_t s = tf_idx(L, pg, mI + t);
+#pragma unroll
+            for (int r = 0; r < B; ++r) {
+                const double v = a.xnext[tf_next_x(a, e, p, s2, t * B + r, MP * B)];
+                xn[t][r] = v;
+                a.x[(int64_t)r * L.plane + s] = v;
+            }
+        }
+    }
+    // the factors of the first streamed nodes are requested before the middle system is solved
+    struct Node { double y[B]; double U[MP][B][B]; };
+    auto load = [&](int j, Node& n) { ldU(nat(j), n.U, n.y); };
+    constexpr int D = TF_BACKSUB_DEPTH;
+    Node ring[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (jstart - d >= 0) load(jstart - d, ring[d]);
+    if (hu != 0) {
+        double Tc[NB][NB], Tg[NB];                 // T1^-1 [C1 | g1], rows = down unknowns
+        double S[NB][NB], g2[NB];
+        double Uk[MP][B][B], yk[B];
+        // rows of the down half, last first, substituted into each other (T1 is unit upper triangular)
+#pragma unroll
+        for (int k = MP - 1; k >= 0; --k) {
+            ldU(h - MP + k, Uk, yk);
+#pragma unroll
+            for (int i = 0; i < B; ++i) {
+                Tg[k * B + i] = yk[i];
+#pragma unroll
+                for (int c = 0; c < NB; ++c) { Tc[k * B + i][c] = 0.0; }
+            }
+#pragma unroll
+            for (int c = 0; c < MP; ++c) {
+                const int u = k + 1 + c;           // unknown index over (a, b)
+                if (u >= MP) {
+#pragma unroll
+                    for (int i = 0; i < B; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < B; ++jj) Tc[k * B + i][(u - MP) * B + jj] += Uk[c][i][jj];
+                } else {
+                    // x_u of the down half: replace it by its own row, Tg_u - Tc_u b
+#pragma unroll
+                    for (int i = 0; i < B; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < B; ++jj) {
+                            const double f = Uk[c][i][jj];
+                            Tg[k * B + i] = tf_fma(-f, Tg[u * B + jj], Tg[k * B + i]);
+#pragma unroll
+                            for (int cc = 0; cc < NB; ++cc)
+                                Tc[k * B + i][cc] = tf_fma(-f, Tc[u * B + jj][cc], Tc[k * B + i][cc]);
+                        }
+                }
+            }
+        }
+        // a = Tg - Tc b.  Rows of the up half: x_r + sum_c U'_r[c] x_{r-1-c} = y'_r
+#pragma unroll
+        for (int k = 0; k < MP; ++k) {
+            ldU(h + k, Uk, yk);
+#pragma unroll
+            for (int i = 0; i < B; ++i) {
+                g2[k * B + i] = yk[i];
+#pragma unroll
+                for (int c = 0; c < NB; ++c) S[k * B + i][c] = (c == k * B + i) ? 1.0 : 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < MP; ++c) {
+                const int u = MP + k - 1 - c;      // unknown index over (a, b)
+                if (u >= MP) {
+#pragma unroll
+                    for (int i = 0; i < B; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < B; ++jj) S[k * B + i][(u - MP) * B + jj] += Uk[c][i][jj];
+                } else if (u >= 0) {
+#pragma unroll
+                    for (int i = 0; i < B; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < B; ++jj) {
+                            const double f = Uk[c][i][jj];
+                            g2[k * B + i] = tf_fma(-f, Tg[u * B + jj], g2[k * B + i]);
+#pragma unroll
+                            for (int cc = 0; cc < NB; ++cc)
+                                S[k * B + i][cc] = tf_fma(-f, Tc[u * B + jj][cc], S[k * B + i][cc]);
+                        }
+                }
+            }
+        }
+        if (!tf_dense_solve<NB>(S, g2)) *a.status = 1;
+        // g2 = b; a = Tg - Tc b
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int c = 0; c < NB; ++c) Tg[i] = tf_fma(-Tc[i][c], g2[c], Tg[i]);
+        if (dir == 0) {
+#pragma unroll
+            for (int k = 0; k < MP; ++k) {
+                const int64_t s = tf_idx(L, pg, h - MP + k);
+#pragma unroll
+                for (int r = 0; r < B; ++r) { a.x[(int64_t)r * L.plane + s] = Tg[k * B + r]; xn[k][r] = Tg[k * B + r]; }
+            }
+            // (ahead of node h-MP-1: h-MP (a_0), h-MP+1 (a_1), ...)
+        } else {
+#pragma unroll
+            for (int k = 0; k < MP; ++k) {
+                const int64_t s = tf_idx(L, pg, h + k);
+#pragma unroll
+                for (int r = 0; r < B; ++r) { a.x[(int64_t)r * L.plane + s] = g2[k * B + r]; xn[MP - 1 - k][r] = g2[k * B + r]; }
+            }
+            // (ahead of node h+MP, walking up: h+MP-1 (b_{MP-1}), ...)
+        }
+    }
+    for (int j0 = jstart; j0 >= 0; j0 -= D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int j = j0 - d;
+            if (j < 0) break;
+            const Node& cur = ring[d];
+            const int64_t s = tf_idx(L, pg, nat(j));
+            double x[B];
+#pragma unroll
+            for (int r = 0; r < B; ++r) x[r] = cur.y[r];
+#pragma unroll
+            for (int c = 0; c < MP; ++c) tf_mv_sub<B>(x, cur.U[c], xn[c]);
+#pragma unroll
+            for (int c = MP - 1; c > 0; --c)
 #pragma unroll
                 for (int r = 0; r < B; ++r) xn[c][r] = xn[c - 1][r];
 #pragma unroll
