@@ -209,6 +209,7 @@ struct TfLevelArgs {
     // solved, tfk_l1_fwd2 eliminates the right-hand side again with the separator above known, and
     // the back-substitution uses U alone (tfk_l1_backsub_u).  Chosen per solver (TF_RESPIKE_*).
     int respike;
+    int twist;                     // ... with the down and the up walk sharing every chunk (tf_twist_h)
     double* topAinv;               // [b][b] planes over systems (TfTopArgs::Ainv)
     double* topx;                  // [sys][b]
     // diagnostic builds (-DTF_STAMPS): one workgroup writes s_memtime stamps here (else NULL)
@@ -232,6 +233,8 @@ struct TfTopArgs {                 // final 1-node system per ensemble member
 // on scalar models (config 2 -12 %) and small grids (-5 % at 2e5 nodes): profiles/r02_ab_runs.txt.
 #define TF_RESPIKE_MODEL(mp, nvar) ((mp) * (nvar) * (nvar) >= 8)
 #define TF_RESPIKE_MIN_NODES 750000
+// ... in twisted form while one walk direction leaves SIMDs idle (1024 SIMDs x 64 lanes)
+#define TF_TWIST_MAX_CHUNKS 65536
 
 // nodes per thread of tfk_sweep_f_stage_rhs (the other sweeps: TF_SEG of the code object, 4 or 8).
 // Two register windows per variable make its ghost rows twice as expensive: 8 nodes per thread

@@ -796,13 +796,15 @@ struct TfRowsBT {
 // only 489 wavefronts for 1024 SIMDs.  The factorisation stores the normalised pivot rows U of
 // the down walk for the first h nodes and those of the up walk for the others: the same bytes.
 // Chunks too short for two halves (and blocks too big for the middle system in registers) keep
-// h = mI: the up half is empty and everything reduces to the one-sided form.
+// h = mI: the up half is empty and everything reduces to the one-sided form.  So do solvers whose
+// chunks fill the GPU anyway (a.twist = 0: more than TF_TWIST_MAX_CHUNKS; there the second walk
+// only adds the middle system: 8 members per GPU -3 %, config 5 -1.5 %).
 #ifndef TF_TWIST
 #define TF_TWIST 1
 #endif
 template <int B, int MP>
-TF_DEVICE int tf_twist_h(int mI) {
-    return (TF_TWIST && MP * B <= 6 && mI >= 4 * MP) ? (mI + 1) / 2 : mI;
+TF_DEVICE int tf_twist_h(int mI, int enabled) {
+    return (TF_TWIST && enabled && MP * B <= 6 && mI >= 4 * MP) ? (mI + 1) / 2 : mI;
 }
 
 // ---- interior elimination of one chunk in one direction --------------------
@@ -841,7 +843,7 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
     // the first MP rows, the only ones that couple to it (local order: the node next to the
     // interior is the last one)
     double sa[KNOWN ? MP : 1][B];
-    const int hdn = tf_twist_h<B, MP>(mI);           // nodes of the down half (a.respike)
+    const int hdn = tf_twist_h<B, MP>(mI, a.twist);  // nodes of the down half (a.respike)
     if (KNOWN) {
         const int e = pg / L.P, p = pg - e * L.P;
         const bool has_sep = DIR < 0 || L.periodic || p > 0;
@@ -1472,7 +1474,7 @@ TF_DEVICE void tfk_backsub_twist_body(const TfLevelArgs& a, int pg, int dir) {
     if (pg >= L.Ptot) return;
     const int e = pg / L.P, p = pg - e * L.P;
     const int len = tf_len(L, p), mI = len - MP;
-    const int h = tf_twist_h<B, MP>(mI), hu = mI - h;
+    const int h = tf_twist_h<B, MP>(mI, a.twist), hu = mI - h;
     if (dir == 1 && hu == 0) return;
     double xn[MP][B];                              // the MP solved nodes ahead of the walk, nearest first
     // local index (walking direction) of the first node of the streamed part: one-sided, ahead of

@@ -395,6 +395,7 @@ struct tf_solver {
     // (tfk_sweep_f_stage, tfk_spmv_mon): same operations, same bits.
     bool fuse_stage = true;
     bool l1_respike = false;       // level-1 spike response not stored (tf_args.h, TF_RESPIKE_*)
+    int l1_twist = -1;             // -1: by the number of chunks; 0 / 1: TRIFLOW_L1_TWIST (tests, A/B runs)
     void stage_rhs(const double* Uin, int nterms, const double* const* ks, const double* ac,
                    const double* gc, double dt, double* y, const double* monitor_rhs) {
         if (!fuse_stage || monitor_due(monitor_rhs, nterms, gc)) {
@@ -458,6 +459,7 @@ struct tf_solver {
         a.next_aos = next_aos(l) ? 1 : 0; a.crf = lv.crf.p; a.zt = lv.zt.p;
         a.fold_top = fold_top() && l + 1 == levels.size() ? 1 : 0;
         a.respike = l == 0 && l1_respike ? 1 : 0;
+        a.twist = a.respike && (l1_twist < 0 ? lv.L.Ptot <= TF_TWIST_MAX_CHUNKS : l1_twist > 0) ? 1 : 0;
         a.topAinv = topAinv.p; a.topx = top.x.p;
         a.stamps = stamp_buf.n ? (unsigned long long*)stamp_buf.p + 64 * l : nullptr;
         return a;
@@ -705,6 +707,7 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
     if (const char* v = getenv("TRIFLOW_GRAPHS")) s->graphs_on = tfb::graphs_supported() && atoi(v) != 0;
     if (const char* v = getenv("TRIFLOW_FUSE_STAGE")) s->fuse_stage = atoi(v) != 0;      // A/B runs
     s->l1_respike = TF_RESPIKE_MODEL(sp.mp, sp.nvar) && (int64_t)N * nsys >= TF_RESPIKE_MIN_NODES;
+    if (const char* v = getenv("TRIFLOW_L1_TWIST")) s->l1_twist = atoi(v) != 0 ? 1 : 0;
     if (const char* v = getenv("TRIFLOW_L1_RESPIKE"))                                   // A/B runs, tests
         s->l1_respike = TF_RESPIKE_MODEL(sp.mp, sp.nvar) && atoi(v) != 0;
 
