@@ -204,7 +204,7 @@ def main():
     N = x.size
     model = Model(*workloads.model_args(name))
     ens = Ensemble(model, x, fields, pars, bool(pars["periodic"]), scheme=scheme,
-                   device=device_index, hook=None, nstate=2)
+                   device=device_index, hook=None, nstate=3)
     solver = ens.solver
 
     def barrier():
@@ -221,10 +221,24 @@ def main():
     solver.timing(kernels=[sweep_kernel])
     solver.timing_reset()
     blocks = []
+    # The film model's waves steepen: at dt = 1e-3 config 3 stays smooth for about 6000 steps
+    # (tools/gpu_soak.py), after which the state itself blows up.  Runs longer than MAX_RUN_STEPS
+    # go back to the initial state (Ensemble.restart: one device-to-device copy of the state,
+    # 24 MB per member, queued on the solver's stream) -- between timed blocks, and inside a block
+    # only if a single block is longer than that.
+    MAX_RUN_STEPS = 4000
+    run_steps = args.warmup
     for _ in range(max(args.repeats, 1)):
+        if run_steps + min(args.steps, MAX_RUN_STEPS) > MAX_RUN_STEPS and run_steps > 0:
+            ens.restart()
+            run_steps = 0
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):           # EXACTLY K steps between the two barriers
+            if run_steps >= MAX_RUN_STEPS:
+                ens.restart()
+                run_steps = 0
+            run_steps += 1
             ens.step(dt)
         barrier()
         blocks.append(time.perf_counter() - t0)
@@ -234,6 +248,8 @@ def main():
     report, nprof = {}, 0
     if not args.plain:
         # untimed pass with every launch instrumented: per-kernel breakdown
+        if run_steps + 10 > MAX_RUN_STEPS:
+            ens.restart()
         nprof = min(args.steps, 10)
         solver.timing(True)
         solver.timing_reset()

@@ -679,6 +679,36 @@ def check_unstable_factorisation_is_loud(backend):
     assert refined and omega < 1e-10
 
 
+def check_ensemble_restart(backend):
+    """Ensemble.restart(): back to the initial state on the device (bench.py uses it to keep long
+    runs inside the time range where the film model stays smooth) -- the steps after a restart
+    repeat the first ones bit for bit, BDF-2 included (its history starts over)."""
+    from triflow_amd.ensemble import Ensemble
+    for cfg, sch, hook, N in ((3, "ROS2", None, 3001), (5, "BDF2", DEVICE_HOOKS["cfg5"], 1003),
+                              (1, "Theta", DEVICE_HOOKS["cfg1"], 200)):
+        name, fd, pars, dt, _ = corpus.config_inputs(cfg, N)
+        m = device_model(name, backend)
+        fields = {k: v[None, :] for k, v in fd.items() if k != "x"}
+        ens = Ensemble(m, fd["x"], fields, pars, bool(pars["periodic"]), scheme=sch, hook=hook, nstate=3)
+        runs = []
+        for _ in range(2):
+            for _ in range(7):
+                ens.step(dt)
+            ens.sync()
+            runs.append(ens.state().copy())
+            ens.restart()
+        ens.close()
+        assert np.isfinite(runs[0]).all() and np.array_equal(runs[0], runs[1]), (cfg, sch)
+        two = Ensemble(m, fd["x"], fields, pars, bool(pars["periodic"]), scheme=sch, hook=hook, nstate=2)
+        try:
+            two.restart()
+            raised = False
+        except RuntimeError:
+            raised = True
+        two.close()
+        assert raised
+
+
 def check_fused_stage_rhs(backend):
     """Right-hand side of Rosenbrock stages i >= 1: tfk_sweep_f_stage_rhs (F of the stage state and
     J @ sum gamma k from one window pass) against the two-kernel form it replaces

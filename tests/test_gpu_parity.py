@@ -396,6 +396,10 @@ def test_row_monitor():
     pc.check_row_monitor(HIP)
 
 
+def test_ensemble_restart():
+    pc.check_ensemble_restart(HIP)
+
+
 def test_respike():
     pc.check_respike(HIP)
 

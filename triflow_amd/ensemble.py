@@ -85,6 +85,10 @@ class Ensemble:
             s.set_helpers(np.array([np.broadcast_to(fields[k], (self.nsys, self.N))
                                     for k in model._help_funcs]))
         s.set_state(0, np.array([np.broadcast_to(fields[k], (self.nsys, self.N)) for k in dep]))
+        # a third (or later) state slot keeps the initial state on the device for restart()
+        self._keep = s.nstate - 1 if s.nstate >= 3 else None
+        if self._keep is not None:
+            s.copy_state(0, self._keep)
         if hook is not None:
             s.set_dirichlet(hook.entries(dep, 0.0))
         self.scheme, self.theta = scheme, theta
@@ -94,7 +98,7 @@ class Ensemble:
     def step(self, dt):
         """One fixed step of every member (asynchronous: returns after the launches)."""
         s, src = self.solver, self.cur
-        dst = (src + 1) % s.nstate
+        dst = (src + 1) % (s.nstate if self._keep is None else self._keep)
         if self.scheme == "Theta":
             s.step_theta(src, dst, dt, self.theta)
         elif self.scheme == "BDF2":
@@ -104,6 +108,17 @@ class Ensemble:
                        hook_after=True, want_err=False)
         self.cur = dst
         self.t += dt
+
+    def restart(self):
+        """Back to the initial state and t = 0 (parameters, hook and factorisation plan stay; a
+        device-to-device copy, queued like a step; needs ``nstate >= 3``): long benchmark runs
+        restart instead of integrating a model past the time its solution stays smooth."""
+        if self._keep is None:
+            raise RuntimeError("Ensemble.restart needs nstate >= 3 (the last slot keeps the initial state)")
+        self.solver.copy_state(self._keep, 0)
+        if self.scheme == "BDF2":
+            self.solver.bdf2_reset()
+        self.cur, self.t = 0, 0.0
 
     def sync(self):
         """Wait for the queued steps; raises if a factorisation met a singular pivot
