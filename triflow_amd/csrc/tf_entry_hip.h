@@ -169,27 +169,35 @@ __global__ void __launch_bounds__(64) tfk_l1_fwd2(TfLevelArgs a) {
 // The next level's rows.  When that level keeps records per node (cyclic reduction), the 64
 // rows of a workgroup are collected in LDS and leave as whole records: coalesced stores of
 // 3*b*b contiguous doubles per separator instead of 8 bytes per lane and instruction.
-__global__ void __launch_bounds__(64) tfk_l1_asm_mat(TfLevelArgs a) {
+// One wavefront per separator NODE (the host launches 64 * mp threads per workgroup: wavefront t
+// of a workgroup takes node t of the same 64 separators): a thread's work is a chain of dependent
+// loads of tips and rows, and 31 250 separators are only 489 wavefronts.
+__global__ void __launch_bounds__(64 * TF_MP) tfk_l1_asm_mat(TfLevelArgs a) {
     constexpr int NREC = 3 * TF_B2 * TF_B2, SW = NREC | 1;           // odd stride: no bank conflicts
+    const int lane = threadIdx.x & 63, pg = blockIdx.x * 64 + lane;
+    const int tsel = blockDim.x > 64 ? (int)(threadIdx.x >> 6) : -1;
     if constexpr (SW * 64 * 8 <= 64 * 1024) {
         if (a.next_aos) {
             __shared__ double stage[64 * SW];
-            tfk_asm_body<TfRowsL1, true>(a, TF_GID, stage + threadIdx.x * SW);
+            tfk_asm_body<TfRowsL1, true>(a, pg, stage + lane * SW, tsel);
             __syncthreads();
             // node (e, p) of the next level is record e * Lnext.N + p = pg (Lnext.N == L.P)
             const int pg0 = blockIdx.x * 64;
             const int nrec = a.L.Ptot - pg0 < 64 ? a.L.Ptot - pg0 : 64;
             double* dst = a.Anext + (int64_t)pg0 * 4 * TF_B2 * TF_B2;
-            for (int idx = threadIdx.x; idx < nrec * NREC; idx += 64) {
+            for (int idx = threadIdx.x; idx < nrec * NREC; idx += blockDim.x) {
                 const int t = idx / NREC, off = idx - t * NREC;
                 dst[(int64_t)t * 4 * TF_B2 * TF_B2 + off] = stage[t * SW + off];
             }
             return;
         }
     }
-    tfk_asm_body<TfRowsL1, true>(a, TF_GID);
+    tfk_asm_body<TfRowsL1, true>(a, pg, nullptr, tsel);
 }
-__global__ void __launch_bounds__(64) tfk_l1_asm_rhs(TfLevelArgs a) { tfk_asm_body<TfRowsL1, false>(a, TF_GID); }
+__global__ void __launch_bounds__(64 * TF_MP) tfk_l1_asm_rhs(TfLevelArgs a) {
+    tfk_asm_body<TfRowsL1, false>(a, blockIdx.x * 64 + (threadIdx.x & 63), nullptr,
+                                  blockDim.x > 64 ? (int)(threadIdx.x >> 6) : -1);
+}
 __global__ void __launch_bounds__(64) tfk_l1_backsub(TfLevelArgs a) { tfk_backsub_body<TfRowsL1, true>(a, TF_GID); }
 __global__ void __launch_bounds__(64) tfk_l1_backsub_u(TfLevelArgs a) {
     if constexpr (TF_RESPIKE_MODEL(TF_MP, TF_NVAR)) tfk_backsub_twist_body<TfRowsL1>(a, TF_GID, (int)blockIdx.y);

@@ -1237,7 +1237,7 @@ TF_DEVICE void tfk_bt_col_body(const TfLevelArgs& a, int pg, int dir, int col) {
 // entry point collects the rows of a workgroup in LDS and writes whole records (a thread's own
 // 8-byte stores into records of 4*b*b doubles are the slowest thing this kernel can do).
 template <class Rows, bool MATRIX>
-TF_DEVICE void tfk_asm_body(const TfLevelArgs& a, int pg, double* stage = nullptr) {
+TF_DEVICE void tfk_asm_body(const TfLevelArgs& a, int pg, double* stage = nullptr, int tsel = -1) {
     constexpr int B = Rows::B, MP = Rows::MP, W = 2 * MP + 1, BB = MP * B;
     typedef TfTips<B, MP> Tip;
     const TfLayout& L = a.L;
@@ -1256,6 +1256,7 @@ TF_DEVICE void tfk_asm_body(const TfLevelArgs& a, int pg, double* stage = nullpt
 
 #pragma unroll
     for (int t = 0; t < MP; ++t) {                 // separator node t = chunk node mI + t
+        if (tsel >= 0 && t != tsel) continue;      // (a thread per separator node: tfk_l1_asm_*)
         double row[W][B][B];
         rows.load(mI + t, row);
         double sub[MP][B][B], dia[MP][B][B], sup[MP][B][B], g[B];

@@ -443,6 +443,8 @@ struct tf_solver {
     }
 
     // -------------------------------------------------------- banded solver
+    // level-1 assemble kernels: a wavefront per separator node on the GPU (tf_entry_hip.h)
+    unsigned asm_block() const { return tfb::is_device_build() ? 64u * (unsigned)spec.mp : 64u; }
     Level& next_of(size_t l) { return l + 1 < levels.size() ? *levels[l + 1] : top; }
     TfLevelArgs level_args(size_t l, const double* rhs1, double* x1) {
         Level& lv = *levels[l];
@@ -497,7 +499,7 @@ struct tf_solver {
                 launch(TFK_BT_LU, gc, 2, 64, &a, sizeof(a));
                 if (G == 1) launch(TFK_BT_SPIKE, gc, 2 * (unsigned)ncols, 64, &a, sizeof(a));
             }
-            if (l == 0) launch(TFK_L1_ASM_MAT, gx, 1, 64, &a, sizeof(a));
+            if (l == 0) launch(TFK_L1_ASM_MAT, gx, 1, asm_block(), &a, sizeof(a));
             else launch(TFK_BT_ASM_MAT, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
         }
         if (!fold_top()) { TfTopArgs t = top_args(); launch(TFK_TOP_FACTOR, cdiv((int64_t)nsys * (tfb::coop_group(top.B) == 8 ? 8 : 1), 64), 1, 64, &t, sizeof(t)); }
@@ -535,7 +537,7 @@ struct tf_solver {
             if (l == 0) launch(TFK_L1_SOLVE, gx, 2, 64, &a, sizeof(a));
             else if (levels[l]->cr) { launch(TFK_CR_FWD, (unsigned)a.L.Ptot, 1, cr_block(), &a, sizeof(a)); continue; }
             else launch(TFK_BT_RHS, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 2, 64, &a, sizeof(a));
-            if (l == 0) launch(TFK_L1_ASM_RHS, gx, 1, 64, &a, sizeof(a));
+            if (l == 0) launch(TFK_L1_ASM_RHS, gx, 1, asm_block(), &a, sizeof(a));
             else launch(TFK_BT_ASM_RHS, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
         }
         if (!fold_top()) { TfTopArgs t = top_args(); launch(TFK_TOP_SOLVE, cdiv(nsys, 64), 1, 64, &t, sizeof(t)); }
