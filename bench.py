@@ -152,9 +152,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--repeats", type=int, default=25,
+    ap.add_argument("--repeats", type=int, default=0,
                     help="the timed K-step block is repeated this many times, each bracketed by "
-                         "barrier + synchronize; value / ms_per_step are those of the median block")
+                         "barrier + synchronize; value / ms_per_step are those of the median block.  "
+                         "0 (default): at least 25 blocks and at least 2500 steps in all, so that the "
+                         "GPU is busy for more than a second on the default workload")
     ap.add_argument("--members-per-gpu", type=int, default=1)
     ap.add_argument("--config", type=int, default=3, choices=(2, 3, 5))
     ap.add_argument("--nodes", type=int, default=0, help="override N (default: BASELINE size)")
@@ -166,6 +168,8 @@ def main():
                     help="also time the CPU baseline with this many member processes (ensemble runs)")
     args = ap.parse_args()
 
+    if args.repeats <= 0:          # (a function of the arguments only: the same on every rank)
+        args.repeats = max(25, -(-2500 // max(args.steps, 1)))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

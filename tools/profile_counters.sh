@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=$1; shift
 OUT=gpurun_out/ctr_$TAG
 mkdir -p $OUT
-ARGS="--steps 4 --warmup 1 --no-cpu-baseline --plain $*"
+ARGS="--steps 4 --warmup 1 --repeats 25 --no-cpu-baseline --plain $*"
 pass() {   # name, counters...
     local name=$1; shift
     rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py $ARGS > $OUT/$name.log 2>&1 \
