@@ -145,7 +145,9 @@ def check_respike(backend):
             xs = spla.spsolve(sps.identity(n, format="csc") - c * Jo, rhs)
             # chunk lengths on both sides of the twisted form's limits (tf_twist_h: 4 mp interior nodes)
             for opts in (dict(refine=0), dict(refine=0, m1=8, m_upper=4), dict(refine=0, m1=5),
-                         dict(refine=0, m1=32), dict(refine=0, m1=13, m_upper=5), dict(refine=0, m1=10)):
+                         dict(refine=0, m1=32), dict(refine=0, m1=13, m_upper=5), dict(refine=0, m1=10),
+                         # (chunks of m1 and m1 + 1 nodes in one level: twisted next to one-sided ones)
+                         dict(refine=0, m1=9), dict(refine=0, m1=4)):
                 xv = []
                 for flag in ("1", "0"):
                     def run():
