@@ -125,6 +125,14 @@ int tf_get_J(tf_solver*, double* Jvals /*[nsys][N][nnz], reference pattern order
 int tf_set_csc_map(tf_solver*, const int32_t* map, int64_t n);
 int tf_get_J_mapped(tf_solver*, double* out /*[n]*/);
 
+/* Declares that no Jacobian entry of the model depends on the state or on the node (constant-
+ * coefficient linear models such as the reference README's "k * dxxU - c * dxU"; codegen marks
+ * the entries, spec["j_uniform"]).  The matrix I - c J of a step then only depends on c, the
+ * scalar parameters and dx: the step functions keep the factorisation while those are unchanged
+ * and only solve -- where the reference factorises in every step (schemes.py:148-149, 557).
+ * Any tf_set_param_scalar / tf_set_param_vector / tf_set_dx invalidates it. */
+int tf_set_constant_jacobian(tf_solver*, int32_t on);
+
 /* ---- seam #3: (I - c J) x = b with the Jacobian of the last tf_eval -------- */
 int tf_factor(tf_solver*, double c);
 int tf_solve(tf_solver*, const double* rhs_flat /*[nsys][N*nvar]*/, double* x_flat);

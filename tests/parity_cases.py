@@ -681,6 +681,53 @@ def check_unstable_factorisation_is_loud(backend):
     assert refined and omega < 1e-10
 
 
+def check_constant_matrix_reuse(backend):
+    """Constant-coefficient linear models (every Jacobian entry node- and state-independent: the
+    README's advection-diffusion, the diffusion model of config 2): the step functions keep the
+    factorisation while c, the parameters and dx are unchanged (tf_set_constant_jacobian) -- same
+    states as factorising in every step (to rounding: the right-hand side takes the solve path
+    instead of riding with the factorisation), also across a change of dt, of a parameter and of
+    both, for Theta (+ hook), ROS2 and BDF-2; a model with a state-dependent Jacobian does not
+    qualify."""
+    import os
+    from triflow_amd.ensemble import Ensemble
+    cases = ((1, "Theta", DEVICE_HOOKS["cfg1"], 200), (2, "Theta", None, 3001), (2, "ROS2", None, 1500),
+             (1, "BDF2", DEVICE_HOOKS["cfg1"], 333))
+    for cfg, sch, hook, N in cases:
+        name, fd, pars, dt, _ = corpus.config_inputs(cfg, N)
+        m = device_model(name, backend)
+        fields = {k: v[None, :] for k, v in fd.items() if k != "x"}
+        out = []
+        for reuse in ("1", "0"):
+            os.environ["TRIFLOW_REUSE_FACTOR"] = reuse
+            try:
+                ens = Ensemble(m, fd["x"], fields, pars, bool(pars["periodic"]), scheme=sch, hook=hook, nstate=2)
+            finally:
+                del os.environ["TRIFLOW_REUSE_FACTOR"]
+            assert ens.solver.constant_jacobian == (reuse == "1")
+            states = []
+            kidx = list(m._device.pars).index("k")
+            for k in range(20):
+                if k == 12:
+                    ens.solver.set_param(kidx, 3 * pars["k"])          # the matrix changes: new factorisation
+                ens.step(dt if k < 6 or k >= 16 else 0.5 * dt)         # so does c = theta dt, twice
+                if k in (5, 11, 15, 19):
+                    ens.sync()
+                    states.append(ens.state().copy())
+            ens.close()
+            out.append(states)
+        for a, b in zip(*out):
+            err = np.abs(a - b).max() / np.abs(b).max()
+            assert np.isfinite(a).all() and err <= 1e-12, (cfg, sch, err)
+        # the parameter change took effect (the states after it differ from a run without it)
+        assert np.abs(out[0][2] - out[0][1]).max() > 0
+    name, fd, pars, dt, _ = corpus.config_inputs(3, 300)
+    m = device_model(name, backend)
+    ens = Ensemble(m, fd["x"], {k: v[None, :] for k, v in fd.items() if k != "x"}, pars, True, scheme="ROS2", nstate=2)
+    assert not ens.solver.constant_jacobian
+    ens.close()
+
+
 def check_ensemble_restart(backend):
     """Ensemble.restart(): back to the initial state on the device (bench.py uses it to keep long
     runs inside the time range where the film model stays smooth) -- the steps after a restart

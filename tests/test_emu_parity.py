@@ -104,6 +104,10 @@ def test_row_monitor(backend):
     pc.check_row_monitor(backend)
 
 
+def test_constant_matrix_reuse(backend):
+    pc.check_constant_matrix_reuse(backend)
+
+
 def test_ensemble_restart(backend):
     pc.check_ensemble_restart(backend)
 

@@ -396,6 +396,10 @@ def test_row_monitor():
     pc.check_row_monitor(HIP)
 
 
+def test_constant_matrix_reuse():
+    pc.check_constant_matrix_reuse(HIP)
+
+
 def test_ensemble_restart():
     pc.check_ensemble_restart(HIP)
 

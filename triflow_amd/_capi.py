@@ -64,6 +64,7 @@ SIGNATURES = {
     "tf_get_F": (C.c_int, [C.c_void_p, c_double_p]),
     "tf_get_J": (C.c_int, [C.c_void_p, c_double_p]),
     "tf_set_csc_map": (C.c_int, [C.c_void_p, c_int32_p, C.c_int64]),
+    "tf_set_constant_jacobian": (C.c_int, [C.c_void_p, C.c_int32]),
     "tf_get_J_mapped": (C.c_int, [C.c_void_p, c_double_p]),
     "tf_factor": (C.c_int, [C.c_void_p, C.c_double]),
     "tf_solve": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
@@ -181,6 +182,12 @@ class DeviceSolver:
                       int(self.periodic), C.byref(opts), C.byref(handle))
         self.handle = handle
         self.nstate = nstate if nstate > 0 else 3
+        # constant-coefficient linear model: the factorisation of a step is kept while c and the
+        # parameters are unchanged (tf_set_constant_jacobian)
+        ju = model.spec.get("j_uniform") or []
+        self.constant_jacobian = bool(ju) and all(ju) and os.environ.get("TRIFLOW_REUSE_FACTOR", "1") != "0"
+        if self.constant_jacobian:
+            self.lib.call("tf_set_constant_jacobian", self.handle, 1)
 
     def close(self):
         if self.handle:

@@ -386,7 +386,7 @@ struct tf_solver {
     // y = cF*F + cA*(J @ sum_t vc_t vx_t): stage right-hand side of a ROW scheme in one pass
     // (every monitor_every-th factorisation: the magnitudes make the pass 40 % slower)
     bool monitor_due(const double* monitor_rhs, int nterms, const double* vc) const {
-        return monitor_rhs && nterms == 1 && vc[0] != 0.0 && refine < 0 &&
+        return monitor_rhs && nterms == 1 && vc[0] != 0.0 && refine < 0 && !reused &&
                (refine == -2 || n_factor % monitor_every == monitor_every / 2);
     }
     // Right-hand side of Rosenbrock stage i >= 1,  dt*F(U + sum_j alpha_ij k_j) + dt*(J @ sum_j gamma_ij k_j):
@@ -394,6 +394,13 @@ struct tf_solver {
     // combination of the same k_j loads.  When the monitor is due, the two-kernel form runs
     // (tfk_sweep_f_stage, tfk_spmv_mon): same operations, same bits.
     bool fuse_stage = true;
+    // Constant matrix (tf_set_constant_jacobian: no Jacobian entry depends on the state or the node).
+    // A factorisation made for c stays valid while c, the scalar parameters and dx are what they
+    // were (par_ver counts their uploads); the step functions then only solve (factor_step).
+    bool jconst = false, cf_valid = false, reused = false;
+    double cf_c = 0.0;
+    uint64_t par_ver = 0, cf_ver = 0;
+    bool reuse_ok(double c) const { return jconst && cf_valid && have_jac && cf_c == c && cf_ver == par_ver; }
     bool l1_respike = false;       // level-1 spike response not stored (tf_args.h, TF_RESPIKE_*)
     int l1_twist = -1;             // -1: by the number of chunks; 0 / 1: TRIFLOW_L1_TWIST (tests, A/B runs)
     void stage_rhs(const double* Uin, int nterms, const double* const* ks, const double* ac,
@@ -505,6 +512,7 @@ struct tf_solver {
         if (!fold_top()) { TfTopArgs t = top_args(); launch(TFK_TOP_FACTOR, cdiv((int64_t)nsys * (tfb::coop_group(top.B) == 8 ? 8 : 1), 64), 1, 64, &t, sizeof(t)); }
         have_factor = true;
         ++n_factor;
+        cf_valid = jconst; cf_c = c; cf_ver = par_ver;
         const Checked* like = checked_like(c);
         check_now = refine == -1 && (n_factor <= 4 || !like || n_factor - like->at >= berr_every);
         if (check_now) { fact_checked = false; fact_needs_refine = false; sweeps_needed = 0; }
@@ -515,6 +523,15 @@ struct tf_solver {
         if (!fold_top()) { TfTopArgs t = top_args(); launch(TFK_TOP_SOLVE, cdiv(nsys, 64), 1, 64, &t, sizeof(t)); }
         backsub_chain(rhs1, x1, fold_top());
         polish(rhs1, x1);
+    }
+    // The factorisation of a time step: made, or -- constant matrix, same c and parameters as the
+    // one in memory -- reused, and the right-hand side solved like a later stage's
+    // (schemes.py:148-149, 557: the reference factorises in every step)
+    void factor_step(double c, const double* rhs1, double* x1) {
+        reused = reuse_ok(c);
+        if (!reused) { factor(c, rhs1, x1); return; }
+        have_factor = true;                          // (the sweep of this step reset it)
+        solve(rhs1, x1);
     }
     // skip_last: the last level's back-substitution already ran inside its forward /
     // factor kernel (cyclic-reduction level that folds the top block in)
@@ -886,6 +903,7 @@ int tf_set_param_scalar(tf_solver* s, int32_t k, const double* values) {
     require(k >= 0 && k < s->spec.npar, "tf_set_param_scalar: index");
     require(!((s->spec.parvec_mask >> k) & 1u), "tf_set_param_scalar: parameter compiled as per-node array");
     tfb::h2d(s->parsca.p + (int64_t)k * s->nsys, values, sizeof(double) * s->nsys, s->stream);
+    ++s->par_ver;
     TF_API_END
 }
 int tf_set_param_vector(tf_solver* s, int32_t k, const double* host) {
@@ -894,12 +912,22 @@ int tf_set_param_vector(tf_solver* s, int32_t k, const double* host) {
     require(k >= 0 && k < s->spec.npar, "tf_set_param_vector: index");
     require((s->spec.parvec_mask >> k) & 1u, "tf_set_param_vector: parameter compiled as scalar");
     s->upload_planes(host, s->parvec.p + (int64_t)k * s->plane(), 1);
+    ++s->par_ver;
     TF_API_END
 }
 int tf_set_dx(tf_solver* s, const double* dxv) {
     TF_API_BEGIN
     require(s && dxv, "null argument");
     tfb::h2d(s->dx.p, dxv, sizeof(double) * s->nsys, s->stream);
+    ++s->par_ver;
+    TF_API_END
+}
+int tf_set_constant_jacobian(tf_solver* s, int32_t on) {
+    TF_API_BEGIN
+    require(s, "null solver");
+    s->jconst = on != 0;
+    s->cf_valid = false;
+    s->drop_graphs();
     TF_API_END
 }
 int tf_set_x(tf_solver* s, const double* x) {
@@ -1119,7 +1147,7 @@ void step_theta(tf_solver* s, int32_t src, int32_t dst, double dt, double theta)
     double* U = s->st(dst);
     const double* Uin = s->stage_input(src, U);                    // copy + hook only when there is a hook
     s->sweep_theta(Uin, dt, theta, s->Wrhs.p);                     // F, J, dt*(F - (theta*J)@U) + U
-    s->factor(theta * dt, s->Wrhs.p, U);
+    s->factor_step(theta * dt, s->Wrhs.p, U);
     s->apply_dirichlet(U, true);
 }
 
@@ -1144,7 +1172,7 @@ void step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns, con
             for (int j = 0; j < i; ++j) { ks[j] = s->K[j].p; cs[j] = alpha[i * ns + j]; gs[j] = gamma[i * ns + j]; }
             s->stage_rhs(Uin, i, ks, cs, gs, dt, s->Wrhs.p, i == 1 ? s->F.p : nullptr);
         }
-        if (i == 0) s->factor(gamma[0] * dt, s->F.p, s->K[0].p);      // factorise + first stage
+        if (i == 0) s->factor_step(gamma[0] * dt, s->F.p, s->K[0].p); // factorise + first stage
         else s->solve(s->Wrhs.p, s->K[i].p);
     }
     for (int j = 0; j < ns; ++j) { ks[j] = s->K[j].p; cs[j] = b[j]; }
@@ -1188,8 +1216,9 @@ int tf_step_theta(tf_solver* s, int32_t src, int32_t dst, double dt, double thet
     TF_API_BEGIN
     require(s, "null solver");
     const std::string key = "T|" + std::to_string(src) + ">" + std::to_string(dst) + "|" + bits_of(dt) + "|" +
-        bits_of(theta) + "|" + std::to_string(s->ndir) + "|" + std::to_string(s->sweeps_for(theta * dt)) + "|" + std::to_string(s->refine);
-    s->run_graphed(key, !s->check_due(theta * dt), [&] { step_theta(s, src, dst, dt, theta); });
+        bits_of(theta) + "|" + std::to_string(s->ndir) + "|" + std::to_string(s->sweeps_for(theta * dt)) + "|" + std::to_string(s->refine) +
+        (s->reuse_ok(theta * dt) ? "|u" : "|f");      // (a step that reuses the factorisation is another string of launches)
+    s->run_graphed(key, s->reuse_ok(theta * dt) || !s->check_due(theta * dt), [&] { step_theta(s, src, dst, dt, theta); });
     TF_API_END
 }
 
@@ -1202,10 +1231,10 @@ int tf_step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns,
     std::string key = "R|" + std::to_string(src) + ">" + std::to_string(dst) + "|" + bits_of(dt) + "|" +
         std::to_string(ns) + "|" + std::to_string(hook_after) + "|" + std::to_string(s->ndir) + "|" +
         std::to_string(s->sweeps_for(gamma[0] * dt)) + "|" + std::to_string(s->refine) + "|" + (b_pred && err_out ? "e" : "-") +
-        ((s->n_factor + 1) % s->monitor_every == s->monitor_every / 2 ? "m" : "-");
+        (s->reuse_ok(gamma[0] * dt) ? "u" : ((s->n_factor + 1) % s->monitor_every == s->monitor_every / 2 ? "m" : "-"));
     for (int i = 0; i < ns * ns; ++i) key += bits_of(alpha[i]) + bits_of(gamma[i]);
     for (int i = 0; i < ns; ++i) key += bits_of(b[i]) + (b_pred ? bits_of(b_pred[i]) : std::string("-"));
-    s->run_graphed(key, !s->check_due(gamma[0] * dt), [&] {
+    s->run_graphed(key, s->reuse_ok(gamma[0] * dt) || !s->check_due(gamma[0] * dt), [&] {
         step_row(s, src, dst, dt, ns, alpha, gamma, b, b_pred, hook_after != 0, err_out != nullptr); });
     if (err_out) {
         *err_out = 0.0;
@@ -1279,7 +1308,7 @@ void step_bdf2(tf_solver* s, int32_t src, int32_t dst, double dt, tf_solver::Bdf
     s->sweep_bdf2(Uin, two_step, 1.0 / 3.0, two_step ? (2.0 / 3.0) * dt : dt, s->Wrhs.p, h.Uprev.p);
     h.have_prev = true;
     h.dt_prev = dt;
-    s->factor(two_step ? (2.0 / 3.0) * dt : dt, s->Wrhs.p, s->Wdel.p);
+    s->factor_step(two_step ? (2.0 / 3.0) * dt : dt, s->Wrhs.p, s->Wdel.p);
     const double* ys[2] = {Uin, s->Wdel.p};
     s->vec(TF_VEC_ADD, U, nullptr, 2, ys, nullptr);
     s->apply_dirichlet(U, true);
