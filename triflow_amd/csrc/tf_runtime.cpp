@@ -539,9 +539,10 @@ struct tf_solver {
         for (size_t l = levels.size() - (skip_last ? 1 : 0); l-- > 0;) {
             TfLevelArgs a = level_args(l, rhs1, x1);
             if (l == 0) {
-                // (grid.y = 2: the down and the up half of every chunk, tf_twist_h)
-                if (l1_respike) launch(TFK_L1_FWD2, cdiv(a.L.Ptot, 64), 2, 64, &a, sizeof(a));
-                launch(l1_respike ? TFK_L1_BACKSUB_U : TFK_L1_BACKSUB, cdiv(a.L.Ptot, 64), l1_respike ? 2 : 1, 64, &a, sizeof(a));
+                // (twisted: grid.y = 2, the down and the up half of every chunk, tf_twist_h)
+                const unsigned gy = a.twist ? 2u : 1u;
+                if (l1_respike) launch(TFK_L1_FWD2, cdiv(a.L.Ptot, 64), gy, 64, &a, sizeof(a));
+                launch(l1_respike ? TFK_L1_BACKSUB_U : TFK_L1_BACKSUB, cdiv(a.L.Ptot, 64), gy, 64, &a, sizeof(a));
             }
             else if (levels[l]->cr) launch(TFK_CR_BWD, (unsigned)a.L.Ptot, 1, cr_block(), &a, sizeof(a));
             else launch(TFK_BT_BACKSUB, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
