@@ -55,6 +55,16 @@
 TF_DEVICE int tf_len(const TfLayout& L, int p) { return L.mbase + (p < L.rem ? 1 : 0); }
 TF_DEVICE int tf_start(const TfLayout& L, int p) { return p * L.mbase + (p < L.rem ? p : L.rem); }
 TF_DEVICE int64_t tf_idx(const TfLayout& L, int pg, int i) { return (int64_t)i * L.Ptot + pg; }
+// Element of plane k at byte offset off8 = 8 * tf_idx(...): the plane's base stays in scalar
+// registers and the lane offset is 32 bits wide (global_load/store with saddr: no 64-bit address
+// arithmetic per access).  A plane is smaller than 4 GB (tf_solver_create checks).
+TF_DEVICE unsigned tf_off8(const TfLayout& L, int pg, int i) { return (unsigned)tf_idx(L, pg, i) * 8u; }
+TF_DEVICE double tf_ldp(const double* base, int64_t k, int64_t plane, unsigned off8) {
+    return *(const double*)((const char*)(base + k * plane) + off8);
+}
+TF_DEVICE void tf_stp(double* base, int64_t k, int64_t plane, unsigned off8, double v) {
+    *(double*)((char*)(base + k * plane) + off8) = v;
+}
 
 // element of the node `d` places after node i of chunk (e, p); wraps or clamps
 // at the ends of the system exactly like the ghost cells of
@@ -185,9 +195,10 @@ TF_DEVICE void tfk_sweep_body(const TfSweepArgs& a, int pg, int seg) {
                 }
             }
             const int64_t s = tf_idx(L, pg, i);
+            const unsigned off = (unsigned)s * 8u;          // (tf_off8: scalar plane base + 32-bit lane offset)
 #pragma unroll
             for (int k = 0; k < TF_NPAR; ++k)
-                if (tf_par_is_vec[k]) par[k] = a.parvec[(int64_t)k * L.plane + s];
+                if (tf_par_is_vec[k]) par[k] = tf_ldp(a.parvec, k, L.plane, off);
             double xc = 0.0;
             if (TF_USES_X) xc = a.xcoord[s];
             double Fo[TF_NVAR];
@@ -198,22 +209,24 @@ TF_DEVICE void tfk_sweep_body(const TfSweepArgs& a, int pg, int seg) {
                 for (int v = 0; v < TF_NVAR; ++v) acc[v] = 0.0;
 #pragma unroll
                 for (int k = 0; k < TF_NNZ; ++k) {       // tfk_spmv_body, scale = 1
-                    const double jv = 1.0 * (TF_JU(k) ? ju.v[k] : a.Jv[(int64_t)k * L.plane + s]);
+                    const double jv = 1.0 * (TF_JU(k) ? ju.v[k] : tf_ldp(a.Jv, k, L.plane, off));
                     acc[tf_pat_eq[k]] = acc[tf_pat_eq[k]] +
                         jv * wv[STAGE_RHS ? tf_pat_var[k] : 0][tf_pat_off[k] + TF_MP];
                 }
 #pragma unroll
                 for (int v = 0; v < TF_NVAR; ++v)
-                    a.stage_rhs[(int64_t)v * L.plane + s] = a.cF * (a.fscale * Fo[v]) + a.cA * acc[v];
+                    tf_stp(a.stage_rhs, v, L.plane, off, a.cF * (a.fscale * Fo[v]) + a.cA * acc[v]);
                 continue;
             }
 #pragma unroll
-            for (int v = 0; v < TF_NVAR; ++v) TF_STORE_STREAM(&a.F[(int64_t)v * L.plane + s], a.fscale * Fo[v]);
+            for (int v = 0; v < TF_NVAR; ++v)
+                TF_STORE_STREAM((double*)((char*)(a.F + (int64_t)v * L.plane) + off), a.fscale * Fo[v]);
             if (WITH_J) {
                 double Jo[TF_NNZ > 0 ? TF_NNZ : 1];
                 tf_eval_J(w, par, dx, xc, Jo);
 #pragma unroll
-                for (int k = 0; k < TF_NNZ; ++k) TF_STORE_STREAM(&a.Jv[(int64_t)k * L.plane + s], Jo[k]);
+                for (int k = 0; k < TF_NNZ; ++k)
+                    TF_STORE_STREAM((double*)((char*)(a.Jv + (int64_t)k * L.plane) + off), Jo[k]);
                 if (BDF) {
                     // TF_VEC_BDF2_RHS and the copy of U into the history, per node
 #pragma unroll
@@ -292,7 +305,7 @@ TF_DEVICE double tfk_spmv_body(const TfSpmvArgs& a, int pg, int seg) {
             constexpr bool mon = MON;
 #pragma unroll
             for (int k = 0; k < TF_NNZ; ++k) {       // pattern order = ascending column
-                double jv = a.scale * (TF_JU(k) ? ju.v[k] : a.Jv[(int64_t)k * L.plane + s]);
+                double jv = a.scale * (TF_JU(k) ? ju.v[k] : tf_ldp(a.Jv, k, L.plane, (unsigned)s * 8u));
                 double wv = w[tf_pat_var[k]][tf_pat_off[k] + TF_MP];
                 if (a.absval) { jv = tf_abs(jv); wv = tf_abs(wv); }
                 acc[tf_pat_eq[k]] = acc[tf_pat_eq[k]] + jv * wv;
@@ -683,10 +696,10 @@ struct TfRowsL1 {
     // the values of one block row as they lie in memory; requested ahead of their use
     struct Raw { double jv[TF_NNZ > 0 ? TF_NNZ : 1]; };
     TF_DEVICE_M void request(int i, Raw& r) const {
-        const int64_t s = tf_idx(a.L, pg, i);
+        // (plane base in scalar registers + a 32-bit lane offset: planes are < 4 GB, tf_solver_create)
+        const unsigned off = tf_off8(a.L, pg, i);
 #pragma unroll
-        for (int k = 0; k < TF_NNZ; ++k)
-            r.jv[k] = TF_JU(k) ? ju.v[k] : a.Jv[(int64_t)k * a.L.plane + s];
+        for (int k = 0; k < TF_NNZ; ++k) r.jv[k] = TF_JU(k) ? ju.v[k] : tf_ldp(a.Jv, k, a.L.plane, off);
     }
     TF_DEVICE_M void decode(int i, const Raw& raw, double (&row)[2 * TF_MP + 1][TF_NVAR][TF_NVAR]) const {
 #pragma unroll
@@ -867,9 +880,9 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
         if (jl < mI) {
             const int i = node(jl);
             rows.request(i, pre.raw);
-            const int64_t s = tf_idx(L, pg, i);
+            const unsigned off = tf_off8(L, pg, i);
 #pragma unroll
-            for (int r = 0; r < B; ++r) pre.y[r] = a.rhs ? a.rhs[(int64_t)r * L.plane + s] : 0.0;
+            for (int r = 0; r < B; ++r) pre.y[r] = a.rhs ? tf_ldp(a.rhs, r, L.plane, off) : 0.0;
         }
     };
     auto install = [&](int q, int jl, const Pre& pre) {   // local row jl into window slot q (pivot j = jl - q)
@@ -977,7 +990,7 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
         const bool keep = KNOWN || !a.respike;
         const bool keep_u = a.respike ? (DIR > 0 ? j < hdn : j < mI - hdn) : DIR > 0;
         if (STORE_U || STORE_Y) {
-            const int64_t s = tf_idx(L, pg, node(j));
+            const unsigned off = tf_off8(L, pg, node(j));
             if (STORE_U && keep_u) {
 #pragma unroll
                 for (int c = 0; c < UW; ++c)
@@ -985,14 +998,14 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
                     for (int r = 0; r < B; ++r)
 #pragma unroll
                         for (int k = 0; k < B; ++k) {
-                            a.Ut[(int64_t)((c * B + r) * B + k) * L.plane + s] = Un[c][r][k];
+                            tf_stp(a.Ut, (c * B + r) * B + k, L.plane, off, Un[c][r][k]);
                             if (SPIKE && keep && c < MP)
-                                a.Et[(int64_t)((c * B + r) * B + k) * L.plane + s] = En[SPIKE && c < MP ? c : 0][r][k];
+                                tf_stp(a.Et, (c * B + r) * B + k, L.plane, off, En[SPIKE && c < MP ? c : 0][r][k]);
                         }
             }
             if (STORE_Y && keep) {
 #pragma unroll
-                for (int r = 0; r < B; ++r) a.yt[(int64_t)r * L.plane + s] = yn[r];
+                for (int r = 0; r < B; ++r) tf_stp(a.yt, r, L.plane, off, yn[r]);
             }
         }
         if (HIST >= 0) {
@@ -1483,15 +1496,15 @@ TF_DEVICE void tfk_backsub_twist_body(const TfLevelArgs& a, int pg, int dir) {
     const int jstart = hu == 0 ? mI - 1 : (dir == 0 ? h - MP - 1 : hu - MP - 1);
     auto nat = [&](int j) { return dir == 0 ? j : mI - 1 - j; };
     auto ldU = [&](int node_nat, double (&U)[MP][B][B], double (&y)[B]) {
-        const int64_t s = tf_idx(L, pg, node_nat);
+        const unsigned off = tf_off8(L, pg, node_nat);
 #pragma unroll
-        for (int r = 0; r < B; ++r) y[r] = a.yt[(int64_t)r * L.plane + s];
+        for (int r = 0; r < B; ++r) y[r] = tf_ldp(a.yt, r, L.plane, off);
 #pragma unroll
         for (int c = 0; c < MP; ++c)
 #pragma unroll
             for (int r = 0; r < B; ++r)
 #pragma unroll
-                for (int k = 0; k < B; ++k) U[c][r][k] = a.Ut[(int64_t)((c * B + r) * B + k) * L.plane + s];
+                for (int k = 0; k < B; ++k) U[c][r][k] = tf_ldp(a.Ut, (c * B + r) * B + k, L.plane, off);
     };
     if (hu == 0 || dir == 0) {
         // the chunk's own separator: solved by the next level

@@ -781,6 +781,7 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
     }
     s->L1 = s->levels[0]->L;
     const int64_t plane = s->L1.plane;
+    require(plane < ((int64_t)1 << 29), "tf_solver_create: more than 2^29 nodes per solver (a plane is addressed with 32-bit byte offsets)");
 
     // ---- memory
     int64_t& tot = s->bytes;
