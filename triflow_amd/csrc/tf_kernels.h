@@ -1391,17 +1391,17 @@ TF_DEVICE void tfk_backsub_body(const TfLevelArgs& a, int pg) {
     // HBM latency is paid per chunk, not per node
     struct Node { double y[B]; double U[UW][B][B]; double E[WITH_E ? MP : 1][B][B]; };
     auto load = [&](int j, Node& n) {
-        const int64_t s = tf_idx(L, pg, j);
+        const unsigned off = tf_off8(L, pg, j);
 #pragma unroll
-        for (int r = 0; r < B; ++r) n.y[r] = a.yt[(int64_t)r * L.plane + s];
+        for (int r = 0; r < B; ++r) n.y[r] = tf_ldp(a.yt, r, L.plane, off);
 #pragma unroll
         for (int c = 0; c < UW; ++c)
 #pragma unroll
             for (int r = 0; r < B; ++r)
 #pragma unroll
                 for (int k = 0; k < B; ++k) {
-                    n.U[c][r][k] = a.Ut[(int64_t)((c * B + r) * B + k) * L.plane + s];
-                    if (WITH_E && c < MP) n.E[WITH_E && c < MP ? c : 0][r][k] = a.Et[(int64_t)((c * B + r) * B + k) * L.plane + s];
+                    n.U[c][r][k] = tf_ldp(a.Ut, (c * B + r) * B + k, L.plane, off);
+                    if (WITH_E && c < MP) n.E[WITH_E && c < MP ? c : 0][r][k] = tf_ldp(a.Et, (c * B + r) * B + k, L.plane, off);
                 }
     };
     // TF_BACKSUB_DEPTH nodes of factors in flight per thread: the walk is a chain of loads
