@@ -793,8 +793,12 @@ struct TfRowsBT {
     }
 };
 
+// Rows requested ahead of their use in the level-1 walks: one (0) or two (1).  Two rows hide more
+// latency but cost 2 x (nnz + nvar) registers in kernels that already overflow into AGPRs; with the
+// walks bound by their instruction stream the moves cost more than the latency:
+// one row ahead is 4 % faster on config 3 (tfk_l1_fwd2 63 -> 52 us), 2 % on config 5 / 8 members.
 #ifndef TF_PREFETCH_DEEP
-#define TF_PREFETCH_DEEP(spike) (!(spike))
+#define TF_PREFETCH_DEEP(spike) 0
 #endif
 #ifndef TF_BACKSUB_DEPTH
 #define TF_BACKSUB_DEPTH 3
@@ -918,7 +922,6 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
     };
     // columns c < 0 only occur for the first MP local rows (jl + d < 0); there the
     // window slot q equals jl (pivot 0), so `c = q + d < 0` is exactly that case.
-    // (one row ahead in the factor walks, whose spike columns leave no registers for two)
     constexpr bool DEEP = TF_PREFETCH_DEEP(SPIKE);
     Pre pre0 = {}, pre1 = {};
     request(0, pre0);
