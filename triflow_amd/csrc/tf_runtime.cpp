@@ -106,7 +106,7 @@ struct tf_solver {
     unsigned cr_factor_block(int64_t chunks) const {
         if (top.B <= 2) return 256u;
         const char* v = getenv("TRIFLOW_CR_FACTOR_BLOCK");
-        if (v) return (unsigned)atoi(v);
+        if (v) return atoi(v) >= 512 ? 512u : 256u;      // (the kernel is written for 4 or 8 wavefronts)
         return chunks > 1024 ? 256u : 512u;
     }
     // the last level is a cyclic-reduction level: it handles the top block itself
