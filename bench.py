@@ -78,9 +78,19 @@ def build_problem(cfg, N, table):
     return name, fd["x"], fields, pars, dt, scheme
 
 
+def config_hook(cfg):
+    """The hook of a BASELINE configuration (config 5: Dirichlet values A[0] = A[-1] = 1), as the
+    declarative object that the device applies in place and the oracle calls like any hook."""
+    if cfg == 5:
+        from triflow_amd.device import DirichletHook
+        return DirichletHook(A={0: 1.0, -1: 1.0})
+    return None
+
+
 def _cpu_sample(job):
-    """One worker of the CPU baseline: `nsteps` steps of one member; returns seconds."""
-    cfg, N, scheme_name, fair, nsteps = job
+    """One worker of the CPU baseline: `nsteps` steps of one member; returns (seconds, final
+    state in the reference's node-major order or None)."""
+    cfg, N, scheme_name, fair, nsteps, want_state = job
     from oracle import numpy_path as ora          # the checker, timed as the CPU baseline
     from triflow_amd import Model, workloads
     name, fd, pars, dt, _ = workloads.config_inputs(cfg, N)
@@ -89,14 +99,21 @@ def _cpu_sample(job):
     scheme = {"ROS2": ora.ROS2, "RODASPR": lambda m: ora.RODASPR(m, time_stepping=False),
               "Theta": ora.Theta, "BDF2": ora.BDF2}[scheme_name](model)
     fields = model.fields_template(**fd)
+    hook = config_hook(cfg)
+    kw = dict(hook=hook) if hook is not None else {}
     t = 0.0
     t0 = time.perf_counter()
     for _ in range(nsteps):
-        t, fields = scheme(t, fields, dt, pars)
-    return time.perf_counter() - t0
+        t, fields = scheme(t, fields, dt, pars, **kw)
+    el = time.perf_counter() - t0
+    return el, (np.array(fields.uflat) if want_state else None)
 
 
-def cpu_baseline(cfg, N, scheme_name, fair=False, workers=1):
+#: steps of the CPU baseline sample = steps of the parity check of the same run
+CPU_STEPS = 3
+
+
+def cpu_baseline(cfg, N, scheme_name, fair=False, workers=1, want_state=False):
     """The reference's algorithm (oracle = NumPy/SciPy port of the numpy-compiler
     path + SuperLU) on this box's host cores, full size.  The algorithm is single
     threaded by construction; ``workers`` > 1 integrates that many independent
@@ -104,20 +121,42 @@ def cpu_baseline(cfg, N, scheme_name, fair=False, workers=1):
     user_guide.rst:125-138) and reports their aggregate rate.  ``fair``: the same
     arithmetic without the reference's per-row ``np.stack`` interleave
     (compilers.py:288), so that the comparison is not inflated by that pathology."""
-    nsteps = 2 if fair else 3
-    job = (cfg, N, scheme_name, fair, nsteps)
+    nsteps = 2 if fair else CPU_STEPS
+    job = (cfg, N, scheme_name, fair, nsteps, want_state and workers <= 1)
+    state = None
     if workers <= 1:
-        el = _cpu_sample(job)
+        el, state = _cpu_sample(job)
     else:
         import multiprocessing as mp
         with mp.get_context("spawn").Pool(workers) as pool:
-            el = max(pool.map(_cpu_sample, [job] * workers))       # slowest member, stepping only
-    return dict(value=max(workers, 1) * nsteps / el, unit="steps/s", cores=max(workers, 1), kind="port",
+            el = max(r[0] for r in pool.map(_cpu_sample, [job] * workers))       # slowest member, stepping only
+    out = dict(value=max(workers, 1) * nsteps / el, unit="steps/s", cores=max(workers, 1), kind="port",
                 sample="%d %s steps of the same workload (N=%d)%s, NumPy %s / SciPy SuperLU, "
                        "%s, %.1f s" % (nsteps, scheme_name, N,
                                        " by each of %d member processes" % workers if workers > 1 else "",
                                        np.__version__,
                                        "one thread per member" if workers > 1 else "single thread", el))
+    return (out, state) if want_state else out
+
+
+#: Full-size parity of the headline run: the device state after CPU_STEPS steps from the initial
+#: condition against the oracle state of the cpu_baseline leg (the same steps, the same inputs).
+#: Bounds = 100 x the value measured on MI355X (DESIGN.md section 5): above them the run fails.
+PARITY_BOUND = {2: 1e-7, 3: 2.5e-10, 5: 2e-10}
+
+
+def device_parity(ens, dt, nsteps, ref_uflat):
+    ens.restart()
+    for _ in range(nsteps):
+        ens.step(dt)
+    ens.sync()
+    st = ens.state()                                  # [nvar][nsys][N]
+    u = np.ascontiguousarray(st[:, 0, :].T).reshape(-1)
+    omega, refined = ens.solver.backward_error()
+    return dict(steps=nsteps, rel_err=float(np.abs(u - ref_uflat).max() / np.abs(ref_uflat).max()),
+                backward_error=float(omega), refined=bool(refined),
+                against="oracle/numpy_path.py (reference algorithm, NumPy + SuperLU) on the same inputs, "
+                        "full size, max-norm relative difference of the state")
 
 
 def scheme_api_rate(model, cfg, N, scheme_name, dt, steps=20):
@@ -208,7 +247,7 @@ def main():
     N = x.size
     model = Model(*workloads.model_args(name))
     ens = Ensemble(model, x, fields, pars, bool(pars["periodic"]), scheme=scheme,
-                   device=device_index, hook=None, nstate=3)
+                   device=device_index, hook=config_hook(args.config), nstate=3)
     solver = ens.solver
 
     def barrier():
@@ -279,6 +318,52 @@ def main():
     if not np.isfinite(state).all():
         raise RuntimeError("non-finite state after the timed steps")
 
+    # BASELINE config 4 proper on the 8-GPU node: 64 members, member m on rank m % 8, 8 members per
+    # rank through the same launches (the line's `value` stays the 1-member-per-GPU weak-scaling
+    # figure, so that N = 1 agrees with the one-GPU run).  TRIFLOW_BENCH_CONFIG4=1: rehearsal with
+    # any number of ranks (8 members per rank).
+    config4 = None
+    want4 = (world == 8 and args.members_per_gpu == 1 and args.config == 3 and scheme == "ROS2"
+             and not args.nodes) or os.environ.get("TRIFLOW_BENCH_CONFIG4") == "1"
+    if multi and want4:
+        n4 = 8 * world
+        table4 = member_table(n4, None) if rank == 0 else np.zeros((n4, 3))
+        table4 = broadcast_table(table4)
+        mine4 = shard_members(n4, rank, world)
+        _, x4, fields4, pars4, dt4, _ = build_problem(3, args.nodes or None, table4[mine4])
+        ens4 = Ensemble(model, x4, fields4, pars4, True, scheme="ROS2", device=device_index, nstate=3)
+
+        def barrier4():
+            ens4.sync()
+            dist.barrier()
+            torch.cuda.synchronize()
+        k4, nb4 = 20, 7
+        for _ in range(3):
+            ens4.step(dt4)
+        blocks4 = []
+        for _ in range(nb4):
+            barrier4()
+            t0 = time.perf_counter()
+            for _ in range(k4):
+                ens4.step(dt4)
+            barrier4()
+            blocks4.append(time.perf_counter() - t0)
+        ens4.check()
+        if not np.isfinite(ens4.state()).all():
+            raise RuntimeError("config 4: non-finite state")
+        tb4 = torch.tensor(blocks4, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        g4 = [torch.zeros_like(tb4) for _ in range(world)]
+        dist.all_gather(g4, tb4)
+        per_rank4 = np.stack([g.cpu().numpy() for g in g4])
+        el4 = float(np.median(per_rank4.max(axis=0)))
+        config4 = {"workload": "BASELINE config 4: %d members of config 3 (c = 0.5 + m/64, We = 0.005 (1 + m %% 8), "
+                               "phase 2 pi m/64), member m on rank m %% %d" % (n4, world),
+                   "members": n4, "members_per_rank": [len(shard_members(n4, r, world)) for r in range(world)],
+                   "steps": k4, "blocks": nb4, "ms_per_step": el4 / k4 * 1e3,
+                   "member_steps_per_s": n4 * k4 / el4,
+                   "per_rank": [round(float(len(mine4) * k4 / np.median(r)), 2) for r in per_rank4]}
+        ens4.close()
+
     if rank == 0:
         elapsed = float(np.median(blocks))
         stages = len(ens.tab.b) if ens.tab is not None else 1
@@ -344,16 +429,38 @@ def main():
                                            for r in per_rank]
             if backend == "nccl" and len(set(devices)) != world:
                 raise RuntimeError("ranks share a GPU: %s" % devices)
+        if config4 is not None:
+            out["config4"] = config4
+            if not args.no_cpu_baseline:
+                # the reference's own advice for sweeps (one process per member), on this node's cores
+                import psutil
+                workers = max(1, min(n4, os.cpu_count() or 1,
+                                     int(psutil.virtual_memory().available // (6 << 30))))
+                config4["cpu_baseline_members"] = cpu_baseline(3, N, "ROS2", workers=workers)
         if world == 1 and args.members_per_gpu == 1 and not args.plain:
             out["scheme_api_steps_per_s"] = scheme_api_rate(model, args.config, N, scheme, dt)
+        parity_failed = None
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.config, N, scheme)
+            # member 0 of a one-member run is the BASELINE configuration itself: the oracle's
+            # state after its timed steps pins the device state of this very run
+            check = args.members_per_gpu == 1
+            out["cpu_baseline"], ref_state = cpu_baseline(args.config, N, scheme, want_state=True)
+            if check:
+                out["parity"] = device_parity(ens, dt, CPU_STEPS, ref_state)
+                bound = PARITY_BOUND[args.config]
+                out["parity"]["bound"] = bound
+                if not out["parity"]["rel_err"] <= bound:
+                    parity_failed = "parity: rel_err %.3e > %.1e" % (out["parity"]["rel_err"], bound)
+            del ref_state
             out["cpu_baseline_fair"] = cpu_baseline(args.config, N, scheme, fair=True)
             workers = args.cpu_workers or (min(64, os.cpu_count() or 1) if args.members_per_gpu > 1 else 0)
             if workers > 1:
                 out["cpu_baseline_members"] = cpu_baseline(args.config, N, scheme, workers=workers)
         print(json.dumps(out))
+        if parity_failed:
+            raise SystemExit(parity_failed)
     if multi:
+        dist.barrier()            # (rank 0 may still have been timing the CPU baseline)
         dist.destroy_process_group()
 
 

@@ -112,6 +112,12 @@ def check_linear_solve(name, backend, N, level_opts, c=0.01, tol=1e-9):
             x = solver.solve(rhs)[0]
             err = np.abs(x - xs).max() / np.abs(xs).max()
             assert err <= tol, (name, periodic, opts, solver.describe(), err)
+            # a second factorisation of the same matrix starts from the pivot orders the first one
+            # stored (cyclic-reduction levels, tf_gj_node): the other code path, the same answer
+            solver.factor(c)
+            x2 = solver.solve(rhs)[0]
+            err2 = np.abs(x2 - xs).max() / np.abs(xs).max()
+            assert err2 <= tol, (name, periodic, opts, solver.describe(), "second factorisation", err2)
             y = solver.matvec(rhs)[0]
             assert np.abs(y - Jo @ rhs).max() <= 1e-12 * max(1.0, np.abs(Jo @ rhs).max())
 

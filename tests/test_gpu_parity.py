@@ -60,6 +60,17 @@ def test_linear_solve_block_sizes(name):
     pc.check_linear_solve(name, HIP, 5003, [dict(refine=0, m1=8)], tol=1e-6 if name == "pair4" else 1e-8)
 
 
+def test_linear_solve_b8_four_wavefronts_per_chunk(monkeypatch):
+    """b = mp * nvar = 8 (wide4) with the 256-thread form of tfk_cr_factor -- forced at a small
+    size, and chosen by the runtime on a level of more than 1024 chunks: a chunk hands 2 * 8 * 17 =
+    272 entries to the next level, more than the workgroup has threads (the single-pass
+    store lost the last 16 of them); refinement off, so that nothing can mask a wrong factor."""
+    monkeypatch.setenv("TRIFLOW_CR_FACTOR_BLOCK", "256")
+    pc.check_linear_solve("wide4", HIP, 5003, [dict(refine=0, m1=8)], tol=1e-6)
+    monkeypatch.delenv("TRIFLOW_CR_FACTOR_BLOCK")
+    pc.check_linear_solve("wide4", HIP, 140003, [dict(refine=0, m1=8)], tol=1e-6)
+
+
 @pytest.mark.parametrize("name", ["M3_film", "M5_stiff", "wide4", "six", "bivar"])
 def test_factorisation_is_accurate_without_refinement(name):
     """The automatic refinement must not be what makes a solve right: with it switched
@@ -347,7 +358,8 @@ def test_time_dependent_hook():
 
 # ---- BASELINE configurations against the oracle at sizes it still finishes in seconds ----
 @pytest.mark.parametrize("cfg,N,nsteps,tol", [(2, 10 ** 6, 2, 1e-7), (3, 2 * 10 ** 5, 2, 2.5e-10),
-                                              (5, 4 * 10 ** 5, 3, 2e-11)])
+                                              (5, 4 * 10 ** 5, 3, 2e-11),
+                                              (3, 10 ** 6, 2, 2.5e-10), (5, 2 * 10 ** 6, 3, 2e-10)])
 def test_config_steps_vs_oracle(cfg, N, nsteps, tol):
     """Configs 2 (full size), 3 and 5 (1/5 and 1/10 size, same dx scaling rules as
     corpus.config_inputs): the configured scheme on the device against the oracle
@@ -456,7 +468,8 @@ def test_bench_process_group_one_rank():
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, TRIFLOW_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29591",
-               RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+               RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               TRIFLOW_BENCH_CONFIG4="1")
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--nodes", "20000",
                           "--steps", "5", "--warmup", "2", "--repeats", "3", "--no-cpu-baseline", "--plain"],
                          cwd=root, env=env, capture_output=True, text=True, timeout=600)
@@ -465,6 +478,25 @@ def test_bench_process_group_one_rank():
     assert line["backend"].startswith("nccl") and line["ranks_seen"] == 1 and len(line["devices_seen"]) == 1
     assert line["n_gpus"] == 1 and line["value"] > 0 and len(line["steps_per_s_per_rank"]) == 1
     assert abs(line["steps_per_s_per_rank"][0] - line["value"]) <= 1e-2 * line["value"]
+    # the config-4 block of the 8-rank line (8 members per rank), rehearsed with this one rank
+    c4 = line["config4"]
+    assert c4["members"] == 8 and c4["members_per_rank"] == [8] and c4["member_steps_per_s"] > 0
+    assert len(c4["per_rank"]) == 1
+
+
+def test_bench_line_carries_its_parity():
+    """bench.py holds the device state of its own run to the oracle state of its cpu_baseline leg
+    (same inputs, same steps) and fails above the bound: here at a size the oracle does in a second."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--nodes", "20000",
+                          "--steps", "5", "--warmup", "2", "--repeats", "3", "--plain"],
+                         cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    par = line["parity"]
+    assert par["steps"] == 3 and par["rel_err"] <= par["bound"] and par["backward_error"] < 1e-10, par
+    assert line["cpu_baseline"]["value"] > 0 and line["roofline"]["frac"] > 0
 
 
 def test_python_hook_stays_resident():

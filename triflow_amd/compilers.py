@@ -19,6 +19,7 @@ There is no CPU implementation behind this module: without ``hipcc`` or the
 built ``libtriflow_hip.so`` it raises.
 """
 
+import fcntl
 import json
 import logging
 import os
@@ -114,6 +115,51 @@ def resource_usage(hsaco_path):
         return json.load(f)["kernels"]
 
 
+def _compile_code_object(model, source, tag, hsaco):
+    """hipcc on the generated translation unit -> ``hsaco`` (+ source and resource table next to it)."""
+    global BUILD_COUNT
+    BUILD_COUNT += 1
+    hip = os.path.join(CACHE_DIR, "model_%s.hip" % tag)
+    # ranks of one node may compile the same uncached model at the same time: every
+    # file of the cache appears by rename, never half written
+    hip_tmp = hip + ".%d.tmp" % os.getpid()
+    with open(hip_tmp, "w") as f:
+        f.write(source)
+    os.replace(hip_tmp, hip)
+    tmp = hsaco + ".%d.tmp" % os.getpid()
+    log.info("hipcc: compiling stencil + solver kernels for %s", model._diff_eqs)
+
+    def compile_with(flags):
+        cmd = [_hipcc(), *flags, "-I", CSRC, "--genco", "--no-gpu-bundle-output",
+               "-Rpass-analysis=kernel-resource-usage", "-o", tmp, hip]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("hipcc failed on the generated kernels (%s):\n%s"
+                               % (hip, res.stderr[-4000:]))
+        return _parse_resource_usage(res.stderr)
+
+    flags = list(HIPCC_FLAGS)
+    usage = compile_with(flags)
+    spilled = [k for k, u in usage.items() if u.get("ScratchSize", 0) > 0]
+    if spilled and "-O1" not in flags and "-O0" not in flags \
+            and os.environ.get("TRIFLOW_ALLOW_SCRATCH") != "1":          # (A/B runs)
+        # Round 1 saw wrong solves from solver kernels that spill to scratch at -O2/-O3 (wide
+        # blocks: error 0.3 at -O3, 6e-15 at -O1); round 2 could not reproduce it (DESIGN.md
+        # "compiler notes"), the conservative gate stays: such a model is built at -O1 --
+        # slower, but it spills anyway
+        log.warning("kernels with scratch spills for %s at %s: %s; rebuilding at -O1",
+                    model._diff_eqs, flags[0], spilled)
+        flags = ["-O1"] + [f for f in flags if not f.startswith("-O")]
+        usage = compile_with(flags)
+    meta = os.path.join(CACHE_DIR, "model_%s.json" % tag)
+    with open(meta + ".%d.tmp" % os.getpid(), "w") as f:
+        json.dump(dict(equations=list(model._diff_eqs), flags=flags, kernels=usage,
+                       skeleton=_skeleton_stamp(), hipcc=hipcc_version()), f, indent=1)
+    os.replace(meta + ".%d.tmp" % os.getpid(), meta)
+    os.replace(tmp, hsaco)
+    evict_stale_cache()
+
+
 def build_code_object(model, parvec_mask=0, seg=None, sweep_block=None):
     """Model -> (path of the cached gfx950 code object, spec dict)."""
     seg = seg or int(os.environ.get("TRIFLOW_SWEEP_SEG", "8"))
@@ -128,49 +174,34 @@ def build_code_object(model, parvec_mask=0, seg=None, sweep_block=None):
     os.makedirs(CACHE_DIR, exist_ok=True)
     hsaco = os.path.join(CACHE_DIR, "model_%s.hsaco" % tag)
     if not os.path.exists(hsaco):
-        hip = os.path.join(CACHE_DIR, "model_%s.hip" % tag)
-        # ranks of one node may compile the same uncached model at the same time: every
-        # file of the cache appears by rename, never half written
-        hip_tmp = hip + ".%d.tmp" % os.getpid()
-        with open(hip_tmp, "w") as f:
-            f.write(source)
-        os.replace(hip_tmp, hip)
-        tmp = hsaco + ".%d.tmp" % os.getpid()
-        log.info("hipcc: compiling stencil + solver kernels for %s", model._diff_eqs)
-
-        def compile_with(flags):
-            cmd = [_hipcc(), *flags, "-I", CSRC, "--genco", "--no-gpu-bundle-output",
-                   "-Rpass-analysis=kernel-resource-usage", "-o", tmp, hip]
-            res = subprocess.run(cmd, capture_output=True, text=True)
-            if res.returncode != 0:
-                raise RuntimeError("hipcc failed on the generated kernels (%s):\n%s"
-                                   % (hip, res.stderr[-4000:]))
-            return _parse_resource_usage(res.stderr)
-
-        flags = list(HIPCC_FLAGS)
-        usage = compile_with(flags)
-        spilled = [k for k, u in usage.items() if u.get("ScratchSize", 0) > 0]
-        if spilled and "-O1" not in flags and "-O0" not in flags \
-                and os.environ.get("TRIFLOW_ALLOW_SCRATCH") != "1":          # (A/B runs)
-            # Round 1 saw wrong solves from solver kernels that spill to scratch at -O2/-O3 (wide
-            # blocks: error 0.3 at -O3, 6e-15 at -O1); round 2 could not reproduce it (DESIGN.md
-            # "compiler notes"), the conservative gate stays: such a model is built at -O1 --
-            # slower, but it spills anyway
-            log.warning("kernels with scratch spills for %s at %s: %s; rebuilding at -O1",
-                        model._diff_eqs, flags[0], spilled)
-            flags = ["-O1"] + [f for f in flags if not f.startswith("-O")]
-            usage = compile_with(flags)
-        meta = os.path.join(CACHE_DIR, "model_%s.json" % tag)
-        with open(meta + ".%d.tmp" % os.getpid(), "w") as f:
-            json.dump(dict(equations=list(model._diff_eqs), flags=flags, kernels=usage,
-                           skeleton=_skeleton_stamp(), hipcc=hipcc_version()), f, indent=1)
-        os.replace(meta + ".%d.tmp" % os.getpid(), meta)
-        os.replace(tmp, hsaco)
-        evict_stale_cache()
+        # The ranks of one node may ask for the same uncached model at the same time (8 ranks of a
+        # sweep on a cold cache): one of them compiles, the others wait on the lock and find the
+        # code object.  Every file of the cache still appears by rename, never half written, so a
+        # file system without working locks costs duplicate compilations, not a torn file.
+        lock_path = hsaco + ".lock"
+        with open(lock_path, "w") as lock:
+            try:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+            except OSError:
+                pass
+            try:
+                if not os.path.exists(hsaco):
+                    _compile_code_object(model, source, tag, hsaco)
+            finally:
+                try:
+                    fcntl.flock(lock, fcntl.LOCK_UN)
+                except OSError:
+                    pass
+        try:
+            os.remove(lock_path)
+        except OSError:
+            pass
     return hsaco, spec
 
 
 _hipcc_version = None
+#: hipcc runs on generated kernels in this process (tests: N ranks on a cold cache compile once)
+BUILD_COUNT = 0
 
 
 def hipcc_version():

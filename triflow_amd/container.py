@@ -139,7 +139,9 @@ class TriflowContainer:
         _write_nc(target, self._stack(self._cached), self._metadata)
         self._cached = []
         if self.save == "last":
-            for other in glob.glob(os.path.join(self.path, "data*.nc")):
+            # only the per-flush files, like the reference (container.py:132-135): the merged
+            # data.nc of an earlier run of a container re-opened with mode="a" stays
+            for other in glob.glob(os.path.join(self.path, "data_*.nc")):
                 if other != target:
                     os.remove(other)
 

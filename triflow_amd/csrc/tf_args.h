@@ -202,6 +202,9 @@ struct TfLevelArgs {
     int cr_rhs;                    // tfk_cr_factor: also eliminate the right-hand side
     double* crf;                   // [node][5][b][b]: Dinv, E, F, Ua, Lb of the eliminated node
     double* zt;                    // [node][b]: Dinv * y of the eliminated node
+    // [node] + [system]: pivot order the block inversion of a node (and of the top block) used last
+    // time, 3 bits per block row, 0 = natural order; tried first by the next factorisation (tf_gj_node)
+    unsigned* perm;
     // last cyclic-reduction level (one chunk per system): it also inverts / applies the
     // single block that is left (what tfk_top_* do otherwise)
     int fold_top;
@@ -214,6 +217,10 @@ struct TfLevelArgs {
     double* topx;                  // [sys][b]
     // diagnostic builds (-DTF_STAMPS): one workgroup writes s_memtime stamps here (else NULL)
     unsigned long long* stamps;
+};
+
+struct TfTailArgs {                // tfk_cr_tail: the last two cyclic-reduction levels of a solve in one launch
+    TfLevelArgs lv[2];
 };
 
 struct TfTopArgs {                 // final 1-node system per ensemble member
@@ -254,7 +261,7 @@ enum TfKernel {
     TFK_BT_LU, TFK_BT_SPIKE, TFK_BT_RHS, TFK_BT_ASM_MAT, TFK_BT_ASM_RHS, TFK_BT_BACKSUB,
     TFK_TOP_FACTOR, TFK_TOP_SOLVE, TFK_BERR, TFK_DIFFNORM, TFK_L1_FACTOR_RHS, TFK_SWEEP_F_STAGE,
     TFK_CR_FACTOR, TFK_CR_FWD, TFK_CR_BWD, TFK_POKE, TFK_SWEEP_FJ_THETA, TFK_SWEEP_FJ_BDF2, TFK_SPMV_MON, TFK_GATHER,
-    TFK_SWEEP_F_STAGE_RHS, TFK_L1_FWD2, TFK_L1_BACKSUB_U, TFK_COUNT
+    TFK_SWEEP_F_STAGE_RHS, TFK_L1_FWD2, TFK_L1_BACKSUB_U, TFK_CR_TAIL, TFK_COUNT
 };
 #define TF_KERNEL_NAMES { \
     "tfk_sweep_f", "tfk_sweep_fj", "tfk_spmv", "tfk_vec", "tfk_vec_maxabs", "tfk_perm", "tfk_dirichlet", \
@@ -262,4 +269,4 @@ enum TfKernel {
     "tfk_bt_lu", "tfk_bt_spike", "tfk_bt_rhs", "tfk_bt_asm_mat", "tfk_bt_asm_rhs", "tfk_bt_backsub", \
     "tfk_top_factor", "tfk_top_solve", "tfk_berr", "tfk_diffnorm", "tfk_l1_factor_rhs", "tfk_sweep_f_stage", \
     "tfk_cr_factor", "tfk_cr_fwd", "tfk_cr_bwd", "tfk_poke", "tfk_sweep_fj_theta", "tfk_sweep_fj_bdf2", \
-    "tfk_spmv_mon", "tfk_gather", "tfk_sweep_f_stage_rhs", "tfk_l1_fwd2", "tfk_l1_backsub_u" }
+    "tfk_spmv_mon", "tfk_gather", "tfk_sweep_f_stage_rhs", "tfk_l1_fwd2", "tfk_l1_backsub_u", "tfk_cr_tail" }

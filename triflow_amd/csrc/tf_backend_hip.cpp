@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <thread>
 #include <stdexcept>
 #include <string>
@@ -74,7 +75,28 @@ struct Bounce {
         ok = true;
     }
 };
-Bounce& bounce() { static thread_local Bounce b; return b; }
+// one set per (thread, device): the events belong to the device that was current when they were
+// made, and a thread may drive solvers on several GPUs (SolverOpts.device); released with the thread
+struct BounceSet {
+    std::map<int, Bounce*> by_device;
+    ~BounceSet() {
+        for (auto& kv : by_device) {
+            Bounce* b = kv.second;
+            if (b->ok) { (void)hipEventDestroy(b->ev[0]); (void)hipEventDestroy(b->ev[1]); }
+            if (b->buf[0]) (void)hipHostFree(b->buf[0]);
+            if (b->buf[1]) (void)hipHostFree(b->buf[1]);
+            delete b;
+        }
+    }
+};
+Bounce& bounce() {
+    static thread_local BounceSet set;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    Bounce*& b = set.by_device[dev];
+    if (!b) b = new Bounce();
+    return *b;
+}
 void parallel_copy(void* dst, const void* src, size_t n) {
     constexpr int NT = 4;
     if (n < (1u << 20)) { std::memcpy(dst, src, n); return; }

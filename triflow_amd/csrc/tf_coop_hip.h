@@ -431,8 +431,8 @@ struct TfCrChunk {
     int pg, e, p, len, start, mI, pe, gprev, pprev;
     bool has_prev;
     int64_t nbase;                                // first node record of system e
-    __device__ __forceinline__ TfCrChunk(const TfLayout& L) {
-        pg = blockIdx.x;
+    __device__ __forceinline__ TfCrChunk(const TfLayout& L, int chunk = (int)blockIdx.x) {
+        pg = chunk;
         e = pg / L.P; p = pg - e * L.P;
         len = tf_len(L, p); start = tf_start(L, p);
         mI = len - 1; pe = len;
@@ -523,18 +523,37 @@ __device__ __forceinline__ void tf_load_row(const double* p, bool on, double (&d
 // Rows of the stored reduction that a lane needs in round r are known up front
 // (one task per group and phase), so the solve kernels request all of them
 // before the first round: one memory latency per launch instead of one per round.
+//
+// One WAVEFRONT per chunk: the lanes exchange right-hand sides through the chunk's LDS block
+// (TfCrSolveLds).  LDS executes the instructions of a wavefront in order, so the phases of a
+// chunk need no s_barrier, only that the compiler keeps the order (tf_wave_sync) -- which lets
+// several chunks, each with its own wavefront, share a workgroup (tfk_cr_tail below).
+__device__ __forceinline__ void tf_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int BB> struct TfCrSolveLds {
+    static constexpr int NPOS = TF_CR_MAXLEN + 1;
+    double sYr[NPOS * 2 * BB], sY[NPOS][BB], sZ[NPOS][BB];
+};
+
+// forward elimination of the right-hand side through chunk `pg`; tid = lane of its wavefront
 template <int BB>
-__device__ __forceinline__ void tfk_cr_fwd_coop(const TfLevelArgs& a) {
+__device__ __forceinline__ void tfk_cr_fwd_chunk(const TfLevelArgs& a, int pg, int tid, TfCrSolveLds<BB>& sh) {
     typedef TfCr<BB> C;
-    constexpr int G = C::G, NPOS = C::NPOS, B2 = BB * BB, MAXR = 4;
+    constexpr int G = C::G, B2 = BB * BB, MAXR = 4;
     static_assert(C::MAXLEN <= 16, "round count");
     const TfLayout& L = a.L;
-    const TfCrChunk<BB> ch(L);
-    const int tid = threadIdx.x, grp = tid / G, g = tid % G;
+    const TfCrChunk<BB> ch(L, pg);
+    const int grp = tid / G, g = tid % G;
     const bool row_on = g < BB;
     const int mI = ch.mI, pe = ch.pe, len = ch.len;
-    __shared__ double sYr[NPOS * 2 * BB], sY[NPOS][BB], sZ[NPOS][BB];
+    double (&sY)[TfCrSolveLds<BB>::NPOS][BB] = sh.sY;
+    double (&sZ)[TfCrSolveLds<BB>::NPOS][BB] = sh.sZ;
+    double* sYr = sh.sYr;
 
+    tf_wave_sync();                                  // (the block may still be read by the previous chunk's phases)
     {
         const double* ys = a.rhs + (ch.nbase + ch.start) * 2 * BB;
         for (int i = tid; i < len * 2 * BB; i += 64) sYr[2 * BB + i] = ys[i];
@@ -543,7 +562,7 @@ __device__ __forceinline__ void tfk_cr_fwd_coop(const TfLevelArgs& a) {
 #pragma unroll
     for (int r = 0; r < MAXR; ++r) {
         const int s = 1 << r;
-        const int nA = (mI / s + 1) / 2, nB = mI / (2 * s), nq = mI / s;
+        const int nA = ((mI >> r) + 1) >> 1, nB = mI >> (r + 1), nq = mI >> r;
         const bool onA = s <= mI && grp < nA && row_on;
         const bool onB = s <= mI && grp <= nB && row_on;
         const bool ends = grp == nB;
@@ -558,17 +577,17 @@ __device__ __forceinline__ void tfk_cr_fwd_coop(const TfLevelArgs& a) {
         tf_load_row<BB>(rl, vL, Lb[r]);
         tf_load_row<BB>(rr, vR, Ua[r]);
     }
-    __syncthreads();
+    tf_wave_sync();
     for (int i = tid; i < (len + 1) * BB; i += 64) {
         const int pos = i / BB, r = i - pos * BB;
         sY[pos][r] = pos > 0 ? sYr[pos * 2 * BB + r] + sYr[pos * 2 * BB + BB + r] : 0.0;
     }
-    __syncthreads();
+    tf_wave_sync();
 #pragma unroll
     for (int r = 0; r < MAXR; ++r) {
         const int s = 1 << r;
         if (s <= mI) {
-            const int nA = (mI / s + 1) / 2, nB = mI / (2 * s), nq = mI / s;
+            const int nA = ((mI >> r) + 1) >> 1, nB = mI >> (r + 1), nq = mI >> r;
             if (grp < nA && row_on) {
                 const int k = s * (2 * grp + 1);
                 double z = 0.0;
@@ -577,7 +596,7 @@ __device__ __forceinline__ void tfk_cr_fwd_coop(const TfLevelArgs& a) {
                 sZ[k][g] = z;
                 a.zt[(ch.nbase + ch.node(k)) * BB + g] = z;
             }
-            __syncthreads();
+            tf_wave_sync();
             if (grp <= nB && row_on) {
                 const bool ends = grp == nB;
                 const int aa = 2 * s * (grp + 1);
@@ -594,12 +613,12 @@ __device__ __forceinline__ void tfk_cr_fwd_coop(const TfLevelArgs& a) {
                 if (vL) sY[aL][g] += yl;
                 if (vR) sY[aU][g] += yu;
             }
-            __syncthreads();
+            tf_wave_sync();
         }
     }
     if (a.fold_top) {
         // last level: apply the inverse of the remaining block (tfk_cr_factor_v3) and run
-        // the back-substitution rounds of this level right away (tfk_cr_bwd_coop)
+        // the back-substitution rounds of this level right away (tfk_cr_bwd_chunk)
         double x = 0.0;
         if (row_on && grp == 0) {
             const int nsys = L.Ptot;
@@ -607,19 +626,19 @@ __device__ __forceinline__ void tfk_cr_fwd_coop(const TfLevelArgs& a) {
             for (int c = 0; c < BB; ++c)
                 x = tf_fma(a.topAinv[(int64_t)(g * BB + c) * nsys + ch.e], sY[pe][c] + sY[0][c], x);
         }
-        __syncthreads();
+        tf_wave_sync();
         if (row_on && grp == 0) {
             a.topx[(int64_t)ch.e * BB + g] = x;
             a.x[(ch.nbase + ch.node(pe)) * BB + g] = x;
             sY[pe][g] = x;
             sY[0][g] = ch.has_prev ? x : 0.0;
         }
-        __syncthreads();
+        tf_wave_sync();
 #pragma unroll
         for (int r = MAXR - 1; r >= 0; --r) {
             const int s = 1 << r;
             if (s <= mI) {
-                const int nA = (mI / s + 1) / 2;
+                const int nA = ((mI >> r) + 1) >> 1;
                 if (grp < nA && row_on) {
                     const int k = s * (2 * grp + 1);
                     const int kl = k - s, kr = k + s <= mI ? k + s : pe;
@@ -633,7 +652,7 @@ __device__ __forceinline__ void tfk_cr_fwd_coop(const TfLevelArgs& a) {
                     sY[k][g] = xk;
                     a.x[(ch.nbase + ch.node(k)) * BB + g] = xk;
                 }
-                __syncthreads();
+                tf_wave_sync();
             }
         }
     } else if (row_on && grp < 2) {
@@ -645,21 +664,21 @@ __device__ __forceinline__ void tfk_cr_fwd_coop(const TfLevelArgs& a) {
 
 // back-substitution: the separators that bound the chunk are known
 template <int BB>
-__device__ __forceinline__ void tfk_cr_bwd_coop(const TfLevelArgs& a) {
+__device__ __forceinline__ void tfk_cr_bwd_chunk(const TfLevelArgs& a, int pg, int tid, TfCrSolveLds<BB>& sh) {
     typedef TfCr<BB> C;
-    constexpr int G = C::G, NPOS = C::NPOS, B2 = BB * BB, MAXR = 4;
+    constexpr int G = C::G, B2 = BB * BB, MAXR = 4;
     const TfLayout& L = a.L;
-    const TfCrChunk<BB> ch(L);
-    const int tid = threadIdx.x, grp = tid / G, g = tid % G;
+    const TfCrChunk<BB> ch(L, pg);
+    const int grp = tid / G, g = tid % G;
     const bool row_on = g < BB;
     const int mI = ch.mI, pe = ch.pe;
-    __shared__ double sX[NPOS][BB];
+    double (&sX)[TfCrSolveLds<BB>::NPOS][BB] = sh.sY;
 
     double Er[MAXR][BB], Fr[MAXR][BB], zk[MAXR];
 #pragma unroll
     for (int r = 0; r < MAXR; ++r) {
         const int s = 1 << r;
-        const int nA = (mI / s + 1) / 2;
+        const int nA = ((mI >> r) + 1) >> 1;
         const bool on = s <= mI && grp < nA && row_on;
         const int k = on ? s * (2 * grp + 1) : 1;
         const double* rec = a.crf + (ch.nbase + ch.node(k)) * 5 * B2 + g * BB;
@@ -667,6 +686,7 @@ __device__ __forceinline__ void tfk_cr_bwd_coop(const TfLevelArgs& a) {
         tf_load_row<BB>(rec + 2 * B2, on, Fr[r]);
         zk[r] = on ? a.zt[(ch.nbase + ch.node(k)) * BB + g] : 0.0;
     }
+    tf_wave_sync();
     if (row_on && grp == 0) {
         const double xs = a.xnext[((int64_t)ch.e * a.Lnext.N + ch.p) * BB + g];
         sX[pe][g] = xs;
@@ -674,12 +694,12 @@ __device__ __forceinline__ void tfk_cr_bwd_coop(const TfLevelArgs& a) {
     }
     if (row_on && grp == 1)
         sX[0][g] = ch.has_prev ? a.xnext[((int64_t)ch.e * a.Lnext.N + ch.pprev) * BB + g] : 0.0;
-    __syncthreads();
+    tf_wave_sync();
 #pragma unroll
     for (int r = MAXR - 1; r >= 0; --r) {
         const int s = 1 << r;
         if (s <= mI) {
-            const int nA = (mI / s + 1) / 2;
+            const int nA = ((mI >> r) + 1) >> 1;
             if (grp < nA && row_on) {
                 const int k = s * (2 * grp + 1);
                 const int kl = k - s, kr = k + s <= mI ? k + s : pe;
@@ -692,9 +712,42 @@ __device__ __forceinline__ void tfk_cr_bwd_coop(const TfLevelArgs& a) {
                 sX[k][g] = xk;
                 a.x[(ch.nbase + ch.node(k)) * BB + g] = xk;
             }
-            __syncthreads();
+            tf_wave_sync();
         }
     }
+}
+
+// one chunk per 64-thread workgroup (the launches of the big levels)
+template <int BB>
+__device__ __forceinline__ void tfk_cr_fwd_coop(const TfLevelArgs& a) {
+    __shared__ TfCrSolveLds<BB> sh;
+    tfk_cr_fwd_chunk<BB>(a, (int)blockIdx.x, (int)threadIdx.x, sh);
+}
+template <int BB>
+__device__ __forceinline__ void tfk_cr_bwd_coop(const TfLevelArgs& a) {
+    __shared__ TfCrSolveLds<BB> sh;
+    tfk_cr_bwd_chunk<BB>(a, (int)blockIdx.x, (int)threadIdx.x, sh);
+}
+
+// The two smallest levels of a solve in ONE launch: level T has at most a few chunks per
+// system (8 for N = 1e6), level T+1 is the last one (one chunk, which also applies the inverse of
+// the top block and back-substitutes itself).  As three launches (forward T, forward T+1,
+// backward T) they cost 16 us of launch-to-launch latency for microseconds of work
+// (profiles/r02_solver_levels_trace.txt); here a workgroup per system gives every chunk of
+// level T a wavefront, and the hand-over between the levels is a workgroup barrier.
+#define TF_CR_TAIL_WAVES 8
+template <int BB>
+__device__ __forceinline__ void tfk_cr_tail_coop(const TfTailArgs& t) {
+    __shared__ TfCrSolveLds<BB> sh[TF_CR_TAIL_WAVES];
+    const int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63, e = (int)blockIdx.x;
+    const TfLevelArgs& la = t.lv[0];
+    const TfLevelArgs& lb = t.lv[1];
+    const int P = la.L.P;
+    for (int c = w; c < P; c += TF_CR_TAIL_WAVES) tfk_cr_fwd_chunk<BB>(la, e * P + c, lane, sh[w]);
+    __syncthreads();                                 // level T's share of level T+1's right-hand side is in memory
+    if (w == 0) tfk_cr_fwd_chunk<BB>(lb, e, lane, sh[0]);
+    __syncthreads();                                 // ... and level T+1's solution
+    for (int c = w; c < P; c += TF_CR_TAIL_WAVES) tfk_cr_bwd_chunk<BB>(la, e * P + c, lane, sh[w]);
 }
 
 // ---- top block: one group of 8 lanes inverts the b x b system of one ensemble member

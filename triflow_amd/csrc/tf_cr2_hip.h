@@ -135,6 +135,117 @@ __device__ __forceinline__ int tf_gj_wave(double (&val)[(NC + 7) / 8], int g, in
     return myk;
 }
 
+// ---- Gauss-Jordan in a pivot order known beforehand -----------------------------------------
+// What tf_gj_wave pays per pivot step is the search: key, three DPP steps, v_readlane, and only
+// then the address of the pivot row -- ~630 cycles of one wavefront per step, 3 800 per block
+// (profiles/r02_cr_factor_stamps.txt), for 4 FMAs of work.  The matrices of consecutive
+// factorisations (time steps) differ little, so the order the search found last time is tried
+// first: every node keeps it (TfLevelArgs::perm, 3 bits per block row, 0 = natural order), the
+// lanes load their rows *in that order*, and the elimination runs with pivot k = lane row k:
+// every lane index is a compile-time constant (pivot value: v_readlane, pivot row: two
+// bank-masked DPP moves per dword inside the 8-lane group, no LDS crossbar round trip for it).
+// Partial pivoting bounds the multipliers by 1; here a multiplier above TF_GJ_GROWTH among the
+// rows not yet used (threshold pivoting, SuperLU's u = 1/8) -- or anything non-finite -- sends
+// the wavefront to the search (tf_gj_wave on the rows in natural order), whose order is stored
+// for the next time.
+#ifndef TF_GJ_STATIC
+#define TF_GJ_STATIC 1
+#endif
+#define TF_GJ_GROWTH 8.0
+
+// value of lane k (compile-time) of each 8-lane group, in every lane of the group
+template <int K>
+__device__ __forceinline__ int tf_group8_bcast(int v) {
+    constexpr int q = K & 3, qp = q | (q << 2) | (q << 4) | (q << 6);
+    // the quad that holds lane k: every lane of it takes the value (banks = quads of a 16-lane row);
+    // the other quad of the group mirrors it (row_half_mirror: lane i <- lane 7 - i)
+    constexpr int own = K < 4 ? 0x5 : 0xA, other = K < 4 ? 0xA : 0x5;
+    int t = __builtin_amdgcn_update_dpp(0, v, qp, 0xF, own, false);
+    return __builtin_amdgcn_update_dpp(t, t, 0x141, 0xF, other, false);
+}
+template <int K>
+__device__ __forceinline__ double tf_group8_bcast_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = tf_group8_bcast<K>((int)(unsigned)(b & 0xffffffffll));
+    const int hi = tf_group8_bcast<K>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+// OR over the 8 lanes of a group, result in every lane
+__device__ __forceinline__ unsigned tf_group8_or(unsigned v) {
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);
+    return v;
+}
+
+template <int BB, int NC, int PC0, int KK>
+__device__ __forceinline__ void tf_gj_static_step(double (&val)[(NC + 7) / 8], int g, int h, bool& grow) {
+    constexpr int NJ = (NC + 7) / 8;
+    constexpr int pc = PC0 + KK, ph = pc & 7, pj = pc >> 3;
+    const double pv = tf_readlane_f64(val[pj], (ph << 3) | KK);           // wave-uniform
+    const double rp = tf_rcp_newton(pv);
+    const double mult = tf_bperm_f64(((ph << 3) | g) << 2, val[pj]);      // my row's entry of the pivot column
+    double prow[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) prow[j] = tf_group8_bcast_f64<KK>(val[j]);
+    const double f = mult * rp;
+    if (g > KK && g < BB && !(tf_abs(f) <= TF_GJ_GROWTH)) grow = true;
+    if (g == KK) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) val[j] *= rp;
+    } else {
+        const double f2 = -f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) val[j] = tf_fma(f2, prow[j], val[j]);
+    }
+    if constexpr (KK + 1 < BB) tf_gj_static_step<BB, NC, PC0, KK + 1>(val, g, h, grow);
+}
+
+// Returns false when the order did not hold (growth / non-finite values): the caller repeats
+// the block with the search.  Lane row g ends as row g of the result.
+template <int BB, int NC, int PC0>
+__device__ __forceinline__ bool tf_gj_static(double (&val)[(NC + 7) / 8], int g, int h) {
+    constexpr int NJ = (NC + 7) / 8;
+    bool grow = false;
+    tf_gj_static_step<BB, NC, PC0, 0>(val, g, h, grow);
+    double chk = 0.0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) chk += val[j] - val[j];
+    if (g < BB && !(chk == 0.0)) grow = true;
+    return __builtin_amdgcn_ballot_w64(grow) == 0ull;
+}
+
+// The block inversion of a node with the stored order first (see above).  `load(r, c)` returns
+// entry (r, c) of the augmented block (rows in natural order); returns the row of the result this
+// lane's row ended as.  `code` (wave-uniform) is the node's stored order and is updated.
+template <int BB, int NC, int PC0, class Load>
+__device__ __forceinline__ int tf_gj_node(double (&val)[(NC + 7) / 8], int g, int h, unsigned& code,
+                                          bool& ok, Load load, bool* searched = nullptr) {
+    constexpr int NJ = (NC + 7) / 8;
+#if TF_GJ_STATIC
+    {
+        // perm[g] = ((code >> 3g) & 7) ^ g: the row that serves pivot g
+        const int src = g < BB ? (int)(((code >> (3 * g)) & 7u) ^ (unsigned)g) : 0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) val[j] = load(g < BB ? src : -1, h + 8 * j);
+        if (tf_gj_static<BB, NC, PC0>(val, g, h)) return g;
+    }
+#endif
+    if (searched) *searched = true;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) val[j] = load(g < BB ? g : -1, h + 8 * j);
+    const int myk = tf_gj_wave<BB, NC, PC0>(val, g, h, ok);
+#if TF_GJ_STATIC
+    // the order the search used: pivot myk was served by row g
+    unsigned bits = 0;
+    if (g < BB && h == 0) {
+        if (myk >= 0) bits = ((unsigned)(g ^ myk)) << (3 * myk); else ok = false;
+    }
+    code = (unsigned)__builtin_amdgcn_readfirstlane((int)tf_group8_or(bits));
+#endif
+    return myk;
+}
+
 template <int BB>
 __device__ __forceinline__ void tfk_cr_factor_v3(const TfLevelArgs& a) {
     typedef TfCr2<BB> C;
@@ -153,7 +264,12 @@ __device__ __forceinline__ void tfk_cr_factor_v3(const TfLevelArgs& a) {
     const bool with_rhs = a.cr_rhs != 0;
 
     __shared__ double sRow[NPOS * PS];
+    __shared__ unsigned sPerm[NPOS + 1];           // stored pivot order of the chunk's nodes (tf_gj_node)
     auto row = [&](int pos, int r) { return sRow + pos * PS + r * RS; };
+    unsigned* const perm = a.perm + ch.nbase + ch.start;      // [node]; the top block's follows the nodes
+    if (tid < len) sPerm[tid + 1] = perm[tid];
+    unsigned* const perm_top = a.perm + (int64_t)L.nsys * L.N + ch.e;    // (fold_top: P == 1, one per system)
+    if (a.fold_top && tid == 64) sPerm[0] = *perm_top;
 
     TF_STAMP_REAL(a, 30);
     TF_STAMP(a, 0);
@@ -202,19 +318,22 @@ __device__ __forceinline__ void tfk_cr_factor_v3(const TfLevelArgs& a) {
     bool ok = true;
     TF_STAMP(a, 1);
     int stamp_i = 2;
-    for (int s = 1; s <= mI; s <<= 1) {
+    for (int r = 0; (1 << r) <= mI; ++r) {
+        const int s = 1 << r;
         // ---- phase A: wavefront w inverts node k = s * (2w + 1)
-        const int nA = (mI / s + 1) / 2;             // <= 8
+        const int nA = ((mI >> r) + 1) >> 1;         // <= 8
         for (int t = w; t < nA; t += nw) {
             const int k = s * (2 * t + 1);
-            const double* rk = row(k, gq);
             double val[NJ];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int c = h + 8 * j;
-                val[j] = c < RW ? rk[c] : ((c < NC && c - RW == g) ? 1.0 : 0.0);
-            }
-            const int myk = tf_gj_wave<BB, NC, oD>(val, g, h, ok);
+            unsigned code = sPerm[k];
+            const unsigned code0 = code;
+            bool searched = false;
+            const double* rk0 = row(k, 0);
+            const int myk = tf_gj_node<BB, NC, oD>(val, g, h, code, ok, [&](int rr, int c) {
+                return rr < 0 ? 0.0 : (c < RW ? rk0[rr * RS + c] : ((c < NC && c - RW == rr) ? 1.0 : 0.0)); }, &searched);
+            if (code != code0 && lane == 0) perm[k - 1] = code;
+            TF_COUNT(a, 41);
+            if (searched) TF_COUNT(a, 40);
             // my row is row myk of [E | . | F | z | D^-1]
             if (g < BB) {
                 double* dst = row(k, myk);
@@ -235,10 +354,10 @@ __device__ __forceinline__ void tfk_cr_factor_v3(const TfLevelArgs& a) {
         // ---- phase B: wavefront w updates the neighbours of task t.  Interior a = 2s(t+1):
         //      its L side lost kL = a-s, its U side loses kR = a+s (if there).  Last task: the
         //      L side of the own separator (pe) and the U side of position 0.
-        const int nB = mI / (2 * s);                 // <= 7
+        const int nB = mI >> (r + 1);                // <= 7
         for (int t = w; t <= nB; t += nw) {
             const bool ends = t == nB;
-            const int aa = 2 * s * (t + 1), nq = mI / s;
+            const int aa = 2 * s * (t + 1), nq = mI >> r;
             const int aL = ends ? pe : aa, aU = ends ? 0 : aa;
             const bool vL = ends ? (nq & 1) != 0 : true;
             const bool vR = ends ? true : aa + s <= mI;
@@ -311,8 +430,8 @@ __device__ __forceinline__ void tfk_cr_factor_v3(const TfLevelArgs& a) {
 
     // ---- this chunk's share of the next level's rows: node p gets (L, D, y) of position pe,
     //      node p-1 gets (U, second part of D, second part of y) of position 0
-    if (tid < 2 * BB * NO) {
-        const int side = tid / (BB * NO), rem = tid - side * BB * NO, r = rem / NO, o = rem - r * NO;
+    for (int i = tid; i < 2 * BB * NO; i += NT) {           // (b = 8: 272 entries, more than 4 wavefronts)
+        const int side = i / (BB * NO), rem = i - side * BB * NO, r = rem / NO, o = rem - r * NO;
         const int nn = side == 0 ? ch.p : ch.pprev;
         double* rec = a.Anext + ((int64_t)ch.e * a.Lnext.N + nn) * REC;
         double* rr = a.rhsnext + ((int64_t)ch.e * a.Lnext.N + nn) * 2 * BB;
@@ -328,16 +447,16 @@ __device__ __forceinline__ void tfk_cr_factor_v3(const TfLevelArgs& a) {
         __syncthreads();
         constexpr int NCT = 2 * BB + 1, NJT = (NCT + 7) / 8;     // [S | y | I]
         if (w == 0) {
-            const double* r0 = row(0, gq);
-            const double* rp = row(pe, gq);
+            const double* r0 = row(0, 0);
+            const double* rp = row(pe, 0);
             double val[NJT];
-#pragma unroll
-            for (int j = 0; j < NJT; ++j) {
-                const int c = h + 8 * j;
-                val[j] = c < BB ? rp[oL + c] + rp[oD + c] + r0[oU + c] + r0[oD + c]
-                       : (c == BB ? rp[oY] + r0[oY] : ((c < NCT && c - BB - 1 == g) ? 1.0 : 0.0));
-            }
-            const int myk = tf_gj_wave<BB, NCT, 0>(val, g, h, ok);
+            unsigned code = sPerm[0];
+            const unsigned code0 = code;
+            const int myk = tf_gj_node<BB, NCT, 0>(val, g, h, code, ok, [&](int rr, int c) {
+                const int o = rr * RS;
+                return rr < 0 ? 0.0 : (c < BB ? rp[o + oL + c] + rp[o + oD + c] + r0[o + oU + c] + r0[o + oD + c]
+                       : (c == BB ? rp[o + oY] + r0[o + oY] : ((c < NCT && c - BB - 1 == rr) ? 1.0 : 0.0))); });
+            if (code != code0 && lane == 0) *perm_top = code;
             if (g < BB) {
                 const int nsys = L.Ptot;             // P == 1
 #pragma unroll
@@ -358,10 +477,11 @@ __device__ __forceinline__ void tfk_cr_factor_v3(const TfLevelArgs& a) {
         if (with_rhs) {
             // back-substitution of this level (tfk_cr_bwd_coop): E_k, F_k and z_k are in LDS
             __syncthreads();
-            int s = 1;
-            while (2 * s <= mI) s <<= 1;
-            for (; s >= 1; s >>= 1) {
-                const int nA = (mI / s + 1) / 2;
+            int r = 0;
+            while ((2 << r) <= mI) ++r;
+            for (; r >= 0; --r) {
+                const int s = 1 << r;
+                const int nA = ((mI >> r) + 1) >> 1;
                 for (int t = w; t < nA; t += nw) {
                     if (!(h == 0 && g < BB)) continue;
                     const int k = s * (2 * t + 1);

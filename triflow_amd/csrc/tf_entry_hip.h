@@ -260,5 +260,9 @@ __global__ void __launch_bounds__(TF_CR_BLOCK) tfk_cr_bwd(TfLevelArgs a) {
     if constexpr (TF_B2 <= 2) tfk_crs_bwd<TF_B2>(a);
     else if constexpr (TF_B2 <= 8) tfk_cr_bwd_coop<TF_B2>(a);
 }
+// the last two levels of a solve: one workgroup per system (3 <= b <= 8; the host only launches it there)
+__global__ void __launch_bounds__(64 * TF_CR_TAIL_WAVES) tfk_cr_tail(TfTailArgs t) {
+    if constexpr (TF_B2 >= 3 && TF_B2 <= 8) tfk_cr_tail_coop<TF_B2>(t);
+}
 
 }  // extern "C"

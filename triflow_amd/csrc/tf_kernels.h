@@ -46,9 +46,12 @@
         (a).stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #define TF_STAMP_REAL(a, i) do { if ((a).stamps && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) \
         (a).stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// ... and event counters (every workgroup; one lane per wavefront counts)
+#define TF_COUNT(a, i) do { if ((a).stamps && (threadIdx.x & 63) == 0) atomicAdd(&(a).stamps[i], 1ull); } while (0)
 #else
 #define TF_STAMP(a, i) do {} while (0)
 #define TF_STAMP_REAL(a, i) do {} while (0)
+#define TF_COUNT(a, i) do {} while (0)
 #endif
 
 // ------------------------------------------------------------------- layout

@@ -75,6 +75,8 @@ struct Level {
     bool cr = false;       // cyclic-reduction level (tfk_cr_*), else chunk walks
     DevBuf Ablk, rhs, x, Ut, Et, yt, tips_dn, tips_up, Dinv, Unup;
     DevBuf crf, zt;        // cyclic-reduction levels (records per node, see TfLevelArgs)
+    unsigned* perm = nullptr;   // ... pivot orders of the last factorisation, [nodes + systems]
+    ~Level() { if (perm) tfb::dev_free(perm); }
 };
 
 }  // namespace
@@ -177,13 +179,26 @@ struct tf_solver {
     std::map<std::string, GraphEntry> graphs;
     int64_t graph_clock = 0, graph_replays = 0;
     void drop_graphs() {
+        if (!graphs.empty()) { try { tfb::stream_sync(stream); } catch (...) {} }   // (they may still be queued)
         for (auto& kv : graphs) tfb::graph_destroy(kv.second.graph);
         graphs.clear();
     }
+    // A key is captured when it comes back, not when it is first seen: the adaptive Rosenbrock
+    // schemes call tf_step_row with a new dt in every step, and a capture + instantiation per
+    // step costs more than the ~24 eager launches it would replace.
+    std::map<std::string, int64_t> seen_once;
     template <class Fn> void run_graphed(const std::string& key, bool graphable, Fn fn) {
         if (!graphs_on || !graphable || timing != 0) { fn(); return; }
         auto it = graphs.find(key);
         if (it == graphs.end()) {
+            auto seen = seen_once.find(key);
+            if (seen == seen_once.end()) {
+                if (seen_once.size() >= 64) seen_once.clear();
+                seen_once.emplace(key, ++graph_clock);
+                fn();
+                return;
+            }
+            seen_once.erase(seen);
             tfb::capture_begin(stream);
             mode = TF_CAPTURE;
             try { fn(); } catch (...) { mode = TF_EAGER; tfb::capture_abort(stream); throw; }
@@ -193,6 +208,7 @@ struct tf_solver {
                 auto victim = graphs.begin();
                 for (auto jt = graphs.begin(); jt != graphs.end(); ++jt)
                     if (jt->second.used < victim->second.used) victim = jt;
+                tfb::stream_sync(stream);                           // (it may still be queued)
                 tfb::graph_destroy(victim->second.graph);
                 graphs.erase(victim);
             }
@@ -205,6 +221,14 @@ struct tf_solver {
         }
         it->second.used = ++graph_clock;
         tfb::graph_launch(it->second.graph, stream);
+    }
+    // A step can be replayed when nothing in it waits for the host: no synchronising
+    // backward-error check by the factorisation it makes, and -- constant matrix, the
+    // factorisation in memory reused -- none left over by a tf_factor call without a solve
+    // (polish() checks the first solve of an unchecked factorisation)
+    bool step_graphable(double c) {
+        if (reuse_ok(c)) return refine != -1 || fact_checked;
+        return !check_due(c);
     }
     // will factor(c) want the synchronising backward-error check?  (then the step is not captured)
     bool check_due(double c) {
@@ -465,7 +489,7 @@ struct tf_solver {
         a.tips_dn = lv.tips_dn.p; a.tips_up = lv.tips_up.p;
         a.Lnext = nx.L; a.Anext = nx.Ablk.p; a.rhsnext = nx.rhs.p; a.xnext = nx.x.p;
         a.status = status;
-        a.next_aos = next_aos(l) ? 1 : 0; a.crf = lv.crf.p; a.zt = lv.zt.p;
+        a.next_aos = next_aos(l) ? 1 : 0; a.crf = lv.crf.p; a.zt = lv.zt.p; a.perm = lv.perm;
         a.fold_top = fold_top() && l + 1 == levels.size() ? 1 : 0;
         a.respike = l == 0 && l1_respike ? 1 : 0;
         a.twist = a.respike && (l1_twist < 0 ? lv.L.Ptot <= TF_TWIST_MAX_CHUNKS : l1_twist > 0) ? 1 : 0;
@@ -521,7 +545,7 @@ struct tf_solver {
         if (rhs1 == nullptr) return;
         if (!fused) { solve(rhs1, x1); return; }
         if (!fold_top()) { TfTopArgs t = top_args(); launch(TFK_TOP_SOLVE, cdiv(nsys, 64), 1, 64, &t, sizeof(t)); }
-        backsub_chain(rhs1, x1, fold_top());
+        backsub_chain(rhs1, x1, fold_top() ? 1 : 0);
         polish(rhs1, x1);
     }
     // The factorisation of a time step: made, or -- constant matrix, same c and parameters as the
@@ -533,10 +557,11 @@ struct tf_solver {
         have_factor = true;                          // (the sweep of this step reset it)
         solve(rhs1, x1);
     }
-    // skip_last: the last level's back-substitution already ran inside its forward /
-    // factor kernel (cyclic-reduction level that folds the top block in)
-    void backsub_chain(const double* rhs1, double* x1, bool skip_last) {
-        for (size_t l = levels.size() - (skip_last ? 1 : 0); l-- > 0;) {
+    // skip: that many of the last levels have been back-substituted already (1: the last level
+    // inside its forward / factor kernel -- a cyclic-reduction level that folds the top block
+    // in; 2: the two last levels by tfk_cr_tail)
+    void backsub_chain(const double* rhs1, double* x1, int skip) {
+        for (size_t l = levels.size() - (size_t)skip; l-- > 0;) {
             TfLevelArgs a = level_args(l, rhs1, x1);
             if (l == 0) {
                 // (twisted: grid.y = 2, the down and the up half of every chunk, tf_twist_h)
@@ -548,8 +573,25 @@ struct tf_solver {
             else launch(TFK_BT_BACKSUB, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
         }
     }
+    // The two last levels of a solve go in one launch (tfk_cr_tail) when both are cyclic-reduction
+    // levels of 3 <= b <= 8 and the first of them has a handful of chunks per system
+    bool cr_tail = true;           // (TRIFLOW_CR_TAIL=0: A/B runs)
+    bool tail_ok() const {
+        const size_t n = levels.size();
+        return cr_tail && n >= 3 && top.B >= 3 && top.B <= 8 && levels[n - 1]->cr && levels[n - 2]->cr &&
+               levels[n - 1]->L.P == 1 && levels[n - 2]->L.P <= 16;
+    }
     void solve_once(const double* rhs1, double* x1) {
+        const bool tail = tail_ok();
         for (size_t l = 0; l < levels.size(); ++l) {
+            if (tail && l + 2 == levels.size()) {
+                TfTailArgs t;
+                t.lv[0] = level_args(l, rhs1, x1);
+                t.lv[1] = level_args(l + 1, rhs1, x1);
+                launch(TFK_CR_TAIL, (unsigned)nsys, 1, 64u * 8u, &t, sizeof(t));
+                backsub_chain(rhs1, x1, 2);
+                return;
+            }
             TfLevelArgs a = level_args(l, rhs1, x1);
             unsigned gx = cdiv(a.L.Ptot, 64);
             if (l == 0) launch(TFK_L1_SOLVE, gx, 2, 64, &a, sizeof(a));
@@ -559,7 +601,7 @@ struct tf_solver {
             else launch(TFK_BT_ASM_RHS, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
         }
         if (!fold_top()) { TfTopArgs t = top_args(); launch(TFK_TOP_SOLVE, cdiv(nsys, 64), 1, 64, &t, sizeof(t)); }
-        backsub_chain(rhs1, x1, fold_top());
+        backsub_chain(rhs1, x1, fold_top() ? 1 : 0);
     }
     void refine_sweep(const double* rhs1, double* x1) {
         spmv(x1, Wjv.p, factor_c);                               // c J x
@@ -726,6 +768,7 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
     s->graphs_on = tfb::graphs_supported() && (int64_t)N * nsys <= 50000;
     if (const char* v = getenv("TRIFLOW_GRAPHS")) s->graphs_on = tfb::graphs_supported() && atoi(v) != 0;
     if (const char* v = getenv("TRIFLOW_FUSE_STAGE")) s->fuse_stage = atoi(v) != 0;      // A/B runs
+    if (const char* v = getenv("TRIFLOW_CR_TAIL")) s->cr_tail = atoi(v) != 0;
     s->l1_respike = TF_RESPIKE_MODEL(sp.mp, sp.nvar) && (int64_t)N * nsys >= TF_RESPIKE_MIN_NODES;
     if (const char* v = getenv("TRIFLOW_L1_TWIST")) s->l1_twist = atoi(v) != 0 ? 1 : 0;
     if (const char* v = getenv("TRIFLOW_L1_RESPIKE"))                                   // A/B runs, tests
@@ -813,6 +856,8 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
             lv.x.alloc(nodes * B, tot);
             lv.crf.alloc(nodes * 5 * B * B, tot);
             lv.zt.alloc(nodes * B, tot);
+            lv.perm = (unsigned*)tfb::dev_alloc((nodes + nsys) * sizeof(unsigned));      // (zero-filled)
+            tot += (int64_t)((nodes + nsys) * sizeof(unsigned));
             continue;
         }
         // level 1 of a scalar model exchanges rows inside the band: U is 2*MP wide
@@ -1220,7 +1265,7 @@ int tf_step_theta(tf_solver* s, int32_t src, int32_t dst, double dt, double thet
     const std::string key = "T|" + std::to_string(src) + ">" + std::to_string(dst) + "|" + bits_of(dt) + "|" +
         bits_of(theta) + "|" + std::to_string(s->ndir) + "|" + std::to_string(s->sweeps_for(theta * dt)) + "|" + std::to_string(s->refine) +
         (s->reuse_ok(theta * dt) ? "|u" : "|f");      // (a step that reuses the factorisation is another string of launches)
-    s->run_graphed(key, s->reuse_ok(theta * dt) || !s->check_due(theta * dt), [&] { step_theta(s, src, dst, dt, theta); });
+    s->run_graphed(key, s->step_graphable(theta * dt), [&] { step_theta(s, src, dst, dt, theta); });
     TF_API_END
 }
 
@@ -1236,7 +1281,7 @@ int tf_step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns,
         (s->reuse_ok(gamma[0] * dt) ? "u" : ((s->n_factor + 1) % s->monitor_every == s->monitor_every / 2 ? "m" : "-"));
     for (int i = 0; i < ns * ns; ++i) key += bits_of(alpha[i]) + bits_of(gamma[i]);
     for (int i = 0; i < ns; ++i) key += bits_of(b[i]) + (b_pred ? bits_of(b_pred[i]) : std::string("-"));
-    s->run_graphed(key, s->reuse_ok(gamma[0] * dt) || !s->check_due(gamma[0] * dt), [&] {
+    s->run_graphed(key, s->step_graphable(gamma[0] * dt), [&] {
         step_row(s, src, dst, dt, ns, alpha, gamma, b, b_pred, hook_after != 0, err_out != nullptr); });
     if (err_out) {
         *err_out = 0.0;
