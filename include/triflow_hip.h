@@ -61,7 +61,10 @@ typedef struct tf_solver_opts {
     int32_t device;       /* HIP device ordinal (-1 = current)                      */
     int32_t berr_every;   /* refine = -1: after the first factorisations (and whenever c
                              moves by > 10 %) the backward error is re-measured on every
-                             berr_every-th factorisation (0 = default 8, 1 = always)  */
+                             berr_every-th factorisation (n > 0: that interval, 1 = always;
+                             0 = default: 8, doubling up to 64 while the checks read
+                             rounding level, back to 8 as soon as one does not); halfway
+                             between two checks a Rosenbrock step measures it in passing  */
     int32_t reserved;     /* must be 0 */
 } tf_solver_opts;
 
@@ -192,6 +195,11 @@ int tf_backward_error(tf_solver*, double* omega, int32_t* refined);
  * since the last synchronising call is looked at there (above 1e-11: the next factorisation is
  * checked and refined; above 1e-6: RuntimeError).  This reads it without resetting / raising. */
 int tf_monitor_error(tf_solver*, double* worst);
+/* counters since the solver was created: factorisations made (a step of a constant-matrix model
+ * that finds its factorisation in memory -- one of two, keyed by c -- makes none), backward-error
+ * checks that waited for the device, and factorisations that were redone on longer chunks because
+ * the first attempt lost accuracy */
+int tf_solver_counters(tf_solver*, int64_t* factorisations, int64_t* checks, int64_t* replans);
 int tf_sync(tf_solver*);            /* waits for the stream, reports device-side failures */
 
 /* ---- measurement: kernel begin/end timestamps (HIP events attached to the

@@ -58,7 +58,7 @@ float event_elapsed_ms(Event*, Event*) { return 0.f; }
 typedef TfRowsBT<TF_B2> TfRowsUp;
 
 void launch(Module*, int kernel, unsigned gx, unsigned gy, unsigned block,
-            const void* args, size_t, Stream*) {
+            const void* args, size_t, Stream*, unsigned) {
     const int64_t nthreads = (int64_t)gx * block;
     switch (kernel) {
     case TFK_SWEEP_F: { const auto& a = *(const TfSweepArgs*)args;
@@ -146,8 +146,8 @@ void launch(Module*, int kernel, unsigned gx, unsigned gy, unsigned block,
 }
 
 void launch_timed(Module* m, int kernel, unsigned gx, unsigned gy, unsigned block,
-                  const void* args, size_t n, Stream* s, Event*, Event*) {
-    launch(m, kernel, gx, gy, block, args, n, s);
+                  const void* args, size_t n, Stream* s, Event*, Event*, unsigned) {
+    launch(m, kernel, gx, gy, block, args, n, s, 0);
 }
 
 }  // namespace tfb

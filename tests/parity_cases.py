@@ -260,6 +260,28 @@ def check_bdf2(backend):
             assert err <= 1e-10, (mname, k, err)
 
 
+def check_bdf2_against_vode(backend):
+    """The DEVICE BDF-2 against the reference-generated anchor (tests/golden/vode_bdf.npz: the
+    reference's scipy_ode(vode, bdf) trajectory of the heat equation, oracle/gen_golden.py): close
+    to it at the finest step and converging with order 2 -- the check test_oracle_golden.py makes
+    for the oracle's restatement, here on the scheme the product ships."""
+    g = np.load(os.path.join(GOLDEN, "vode_bdf.npz"))
+    m = device_model("M2_diff", backend)
+    x = g["x"]
+    pars = dict(periodic=True, k=1)
+    errs = []
+    for nsub in (10, 20, 40):
+        scheme = schemes.BDF2(m)
+        fields = m.fields_template(x=x, U=np.cos(x * 2 * np.pi / 10))
+        t = 0.0
+        for _ in range(10 * nsub):
+            t, fields = scheme(t, fields, 0.1 / nsub, pars)
+        errs.append(np.abs(fields.uflat - g["U"][-1]).max())
+    assert errs[0] < 1e-3
+    order = np.log2(errs[0] / errs[1]), np.log2(errs[1] / errs[2])
+    assert 1.6 < order[0] < 2.4 and 1.6 < order[1] < 2.4, (errs, order)
+
+
 def check_bdf2_interleaved(backend):
     """Two BDF2 objects stepping alternately on one model share one device solver; each
     keeps its own history U_{n-1}: both trajectories equal their solo runs bit for bit.  A
@@ -732,6 +754,51 @@ def check_constant_matrix_reuse(backend):
     ens = Ensemble(m, fd["x"], {k: v[None, :] for k, v in fd.items() if k != "x"}, pars, True, scheme="ROS2", nstate=2)
     assert not ens.solver.constant_jacobian
     ens.close()
+
+
+def check_two_resident_factorisations(backend):
+    """The step-doubling controller that the reference wraps around every scheme alternates a
+    coarse step m*dt and fine steps dt (schemes.py:33-66).  For a constant-matrix model the solver
+    keeps TWO factorisations, keyed by c: after the first trial no step factorises again, whatever
+    the order of the two step sizes; a third step size takes the place of the one used longest ago;
+    a parameter upload invalidates both.  Same states as factorising in every step."""
+    import os
+    from triflow_amd.ensemble import Ensemble
+    for cfg, sch, hook, N in ((1, "Theta", DEVICE_HOOKS["cfg1"], 200), (2, "ROS2", None, 1500)):
+        name, fd, pars, dt, _ = corpus.config_inputs(cfg, N)
+        m = device_model(name, backend)
+        fields = {k: v[None, :] for k, v in fd.items() if k != "x"}
+        pattern = ([10 * dt] + [dt] * 10) * 3 + [0.5 * dt, dt, 10 * dt, 0.5 * dt]
+        out, counts = [], []
+        for reuse in ("1", "0"):
+            os.environ["TRIFLOW_REUSE_FACTOR"] = reuse
+            try:
+                ens = Ensemble(m, fd["x"], fields, pars, bool(pars["periodic"]), scheme=sch, hook=hook, nstate=2)
+            finally:
+                del os.environ["TRIFLOW_REUSE_FACTOR"]
+            marks = []
+            for k, h in enumerate(pattern):
+                ens.step(h)
+                if k in (10, 32, len(pattern) - 1):
+                    ens.sync()
+                    marks.append((ens.state().copy(), ens.solver.counters()["factorisations"]))
+            kidx = list(m._device.pars).index("k")
+            ens.solver.set_param(kidx, 2 * pars["k"])
+            ens.step(dt)
+            ens.step(10 * dt)
+            ens.sync()
+            marks.append((ens.state().copy(), ens.solver.counters()["factorisations"]))
+            ens.close()
+            out.append([s for s, _ in marks])
+            counts.append([c for _, c in marks])
+        for a, b in zip(*out):
+            err = np.abs(a - b).max() / np.abs(b).max()
+            assert np.isfinite(a).all() and err <= 1e-12, (cfg, sch, err)
+        # two factorisations for the three trials; then 0.5 dt replaces 10 dt (used longest ago), dt is
+        # still there, 10 dt is made again in the place of 0.5 dt (dt was used after it), and so is the
+        # second 0.5 dt; the new parameter costs one factorisation per step size
+        assert counts[0] == [2, 2, 5, 7], counts[0]
+        assert counts[1][2] == len(pattern), counts[1]
 
 
 def check_ensemble_restart(backend):

@@ -59,6 +59,14 @@ def test_bdf2_interleaved(backend):
     pc.check_bdf2_interleaved(backend)
 
 
+def test_two_resident_factorisations(backend):
+    pc.check_two_resident_factorisations(backend)
+
+
+def test_bdf2_against_vode(backend):
+    pc.check_bdf2_against_vode(backend)
+
+
 def test_simulation_golden(backend):
     pc.check_simulation_golden(backend)
 

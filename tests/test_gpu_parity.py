@@ -105,6 +105,10 @@ def test_bdf2_interleaved():
     pc.check_bdf2_interleaved(HIP)
 
 
+def test_bdf2_against_vode():
+    pc.check_bdf2_against_vode(HIP)
+
+
 def test_simulation_golden():
     pc.check_simulation_golden(HIP)
 
@@ -359,12 +363,13 @@ def test_time_dependent_hook():
 # ---- BASELINE configurations against the oracle at sizes it still finishes in seconds ----
 @pytest.mark.parametrize("cfg,N,nsteps,tol", [(2, 10 ** 6, 2, 1e-7), (3, 2 * 10 ** 5, 2, 2.5e-10),
                                               (5, 4 * 10 ** 5, 3, 2e-11),
-                                              (3, 10 ** 6, 2, 2.5e-10), (5, 2 * 10 ** 6, 3, 2e-10)])
+                                              (3, 10 ** 6, 2, 2e-8), (5, 2 * 10 ** 6, 3, 4e-10)])
 def test_config_steps_vs_oracle(cfg, N, nsteps, tol):
     """Configs 2 (full size), 3 and 5 (1/5 and 1/10 size, same dx scaling rules as
     corpus.config_inputs): the configured scheme on the device against the oracle
-    (reference algorithm + SuperLU).  Tolerances = 100 x the measured difference
-    (1.4e-9, 2.6e-12, 1.7e-13 on MI355X; the measured value is printed and shown on failure).
+    (reference algorithm + SuperLU); config 3 also at its full size (the metric's configuration)
+    and config 5 at half of it.  Tolerances = 100 x the measured difference (1.4e-9, 2.6e-12,
+    1.7e-13, 1.6e-10, 3.4e-12 on MI355X; the measured value is printed and shown on failure).
     The differences are cond(A)*eps of the two direct solvers: config 2 at N = 1e6 has
     cond(I - dt J) = 4e7."""
     from oracle import numpy_path as ora
@@ -408,6 +413,10 @@ def test_row_monitor():
     pc.check_row_monitor(HIP)
 
 
+def test_two_resident_factorisations():
+    pc.check_two_resident_factorisations(HIP)
+
+
 def test_constant_matrix_reuse():
     pc.check_constant_matrix_reuse(HIP)
 
@@ -418,6 +427,29 @@ def test_ensemble_restart():
 
 def test_respike():
     pc.check_respike(HIP)
+
+
+@pytest.mark.parametrize("m1", [32, 13, 9])
+def test_fused_level1_backsub_equals_two_launches(m1, monkeypatch):
+    """tfk_l1_fwd2_backsub (second elimination and back-substitution of the twisted form in one
+    launch, y in LDS) does the arithmetic of tfk_l1_fwd2 + tfk_l1_backsub_u: the same bits, on
+    chunk lengths that are split in two, and on a level that mixes split and one-sided chunks."""
+    from triflow_amd.ensemble import Ensemble
+    name, fd, pars, dt, _ = corpus.config_inputs(3, 3001)
+    m = pc.device_model(name, HIP)
+    fields = {k: np.repeat(v[None, :], 2, axis=0) * (1 + 0.01 * np.arange(2))[:, None]
+              for k, v in fd.items() if k != "x"}
+    out = []
+    monkeypatch.setenv("TRIFLOW_L1_RESPIKE", "1")
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("TRIFLOW_L1_FUSE_BACKSUB", fuse)
+        ens = Ensemble(m, fd["x"], fields, pars, True, scheme="RODASPR", nstate=2, m1=m1)
+        for _ in range(4):
+            ens.step(dt)
+        ens.sync()
+        out.append(ens.state().copy())
+        ens.close()
+    assert np.isfinite(out[0]).all() and np.array_equal(out[0], out[1])
 
 
 def test_fused_stage_rhs():

@@ -33,5 +33,7 @@ for l in range(1, len(s.describe()["chunks"])):
     print("level %d: %d cycles = %.2f us (clock %.2f GHz)  load %d | rounds (A, B): %s | share %d | fold/end %d"
           % (l + 1, total, real, total / real / 1e3 if real else 0, d[0],
              " ".join("(%d, %d)" % (d[1 + 2 * i], d[2 + 2 * i]) for i in range((len(d) - 3) // 2)), d[-2], d[-1]))
+    if r[50]:
+        print("         tail kernel (this level + the last one): " + " ".join(str(int(v)) for v in np.diff(r[50:57])) + " cycles (requests, forward, park, last level, barrier, backward)")
     if r[41]:
         print("         block inversions %d, of which with the pivot search %d (all steps so far)" % (r[41], r[40]))

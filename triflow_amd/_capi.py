@@ -83,6 +83,7 @@ SIGNATURES = {
                                    C.c_int32, C.c_int32, C.POINTER(Scheme), C.c_int32, c_double_p]),
     "tf_backward_error": (C.c_int, [C.c_void_p, c_double_p, c_int32_p]),
     "tf_monitor_error": (C.c_int, [C.c_void_p, c_double_p]),
+    "tf_solver_counters": (C.c_int, [C.c_void_p, c_int64_p, c_int64_p, c_int64_p]),
     "tf_sync": (C.c_int, [C.c_void_p]),
     "tf_timing_enable": (C.c_int, [C.c_void_p, C.c_int64]),
     "tf_timing_reset": (C.c_int, [C.c_void_p]),
@@ -395,6 +396,12 @@ class DeviceSolver:
         om, flag = C.c_double(0.0), C.c_int32(0)
         self.lib.call("tf_backward_error", self.handle, C.byref(om), C.byref(flag))
         return om.value, bool(flag.value)
+
+    def counters(self):
+        """dict(factorisations, checks, replans) since the solver was created."""
+        f, c, r = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self.lib.call("tf_solver_counters", self.handle, C.byref(f), C.byref(c), C.byref(r))
+        return dict(factorisations=f.value, checks=c.value, replans=r.value)
 
     def monitor_error(self):
         """Worst backward error seen by the in-pass monitor of the Rosenbrock steps since the last

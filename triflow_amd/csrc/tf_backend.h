@@ -37,13 +37,15 @@ Stream* stream_create();
 void stream_destroy(Stream* s);
 void stream_sync(Stream* s);
 
-// one launch: grid (gx, gy, 1), block (block, 1, 1), one by-value argument struct
+// one launch: grid (gx, gy, 1), block (block, 1, 1), one by-value argument struct;
+// lds_bytes: dynamic LDS of the workgroup (extern __shared__)
 void launch(Module* m, int kernel, unsigned gx, unsigned gy, unsigned block,
-            const void* args, size_t arg_bytes, Stream* s);
+            const void* args, size_t arg_bytes, Stream* s, unsigned lds_bytes = 0);
 // same launch; `start` / `stop` receive the kernel's own begin / end timestamps
 // (not the stream-order interval around it)
 void launch_timed(Module* m, int kernel, unsigned gx, unsigned gy, unsigned block,
-                  const void* args, size_t arg_bytes, Stream* s, Event* start, Event* stop);
+                  const void* args, size_t arg_bytes, Stream* s, Event* start, Event* stop,
+                  unsigned lds_bytes = 0);
 
 // Stream capture into an executable graph (HIP graphs): a step of a small problem is a string of
 // launch-bound kernels, replayed with one call.  The emulation has none (graphs_supported()).

@@ -214,20 +214,21 @@ void stream_destroy(Stream* s) { if (s) { (void)hipStreamDestroy(s->s); delete s
 void stream_sync(Stream* s) { TF_HIP(hipStreamSynchronize(s->s)); }
 
 void launch(Module* m, int kernel, unsigned gx, unsigned gy, unsigned block,
-            const void* args, size_t arg_bytes, Stream* s) {
+            const void* args, size_t arg_bytes, Stream* s, unsigned lds_bytes) {
     size_t size = arg_bytes;
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<void*>(args),
                       HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-    TF_HIP(hipModuleLaunchKernel(m->fn[kernel], gx, gy, 1, block, 1, 1, 0, s->s, nullptr, config));
+    TF_HIP(hipModuleLaunchKernel(m->fn[kernel], gx, gy, 1, block, 1, 1, lds_bytes, s->s, nullptr, config));
 }
 
 void launch_timed(Module* m, int kernel, unsigned gx, unsigned gy, unsigned block,
-                  const void* args, size_t arg_bytes, Stream* s, Event* start, Event* stop) {
+                  const void* args, size_t arg_bytes, Stream* s, Event* start, Event* stop,
+                  unsigned lds_bytes) {
     size_t size = arg_bytes;
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<void*>(args),
                       HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
     // hipExtModuleLaunchKernel takes the global size in work-items
-    TF_HIP(hipExtModuleLaunchKernel(m->fn[kernel], gx * block, gy, 1, block, 1, 1, 0, s->s,
+    TF_HIP(hipExtModuleLaunchKernel(m->fn[kernel], gx * block, gy, 1, block, 1, 1, lds_bytes, s->s,
                                     nullptr, config, start->e, stop->e, 0));
 }
 

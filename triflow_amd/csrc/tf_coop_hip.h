@@ -538,14 +538,38 @@ template <int BB> struct TfCrSolveLds {
     double sYr[NPOS * 2 * BB], sY[NPOS][BB], sZ[NPOS][BB];
 };
 
-// forward elimination of the right-hand side through chunk `pg`; tid = lane of its wavefront
+// Where a chunk's solve reads and writes (global memory in the one-chunk-per-workgroup launches;
+// tfk_cr_tail hands the right-hand sides and solutions between its two levels through LDS)
+template <int BB> struct TfCrIo {
+    const double* ys;        // right-hand side records of the chunk's nodes [len][2][b] (two parts, summed)
+    const double* crf0;      // stored reduction, record of the chunk's first node ([node][5][b][b])
+    double* next_own;        // forward: part 0 of next-level node p   [b]   (not with fold_top)
+    double* next_prev;       //          part 1 of next-level node p-1 [b]
+    double* xmirror;         // fold_top: a second copy of the solution [node][b] (or NULL)
+    const double* xn_own;    // backward: solution of next-level node p [b], of node p-1 (NULL: none)
+    const double* xn_prev;
+    __device__ __forceinline__ TfCrIo(const TfLevelArgs& a, const TfCrChunk<BB>& ch) {
+        ys = a.rhs + (ch.nbase + ch.start) * 2 * BB;
+        crf0 = a.crf + (ch.nbase + ch.start) * 5 * BB * BB;
+        next_own = a.rhsnext ? a.rhsnext + ((int64_t)ch.e * a.Lnext.N + ch.p) * 2 * BB : nullptr;
+        next_prev = a.rhsnext ? a.rhsnext + ((int64_t)ch.e * a.Lnext.N + ch.pprev) * 2 * BB + BB : nullptr;
+        xmirror = nullptr;
+        xn_own = a.xnext ? a.xnext + ((int64_t)ch.e * a.Lnext.N + ch.p) * BB : nullptr;
+        xn_prev = (a.xnext && ch.has_prev) ? a.xnext + ((int64_t)ch.e * a.Lnext.N + ch.pprev) * BB : nullptr;
+    }
+};
+
+// forward elimination of the right-hand side through chunk `ch`; tid = lane of its wavefront.
+// zkeep[r] (optional): z of this lane's task of round r stays in a register for the
+// back-substitution of the same launch.
 template <int BB>
-__device__ __forceinline__ void tfk_cr_fwd_chunk(const TfLevelArgs& a, int pg, int tid, TfCrSolveLds<BB>& sh) {
+__device__ __forceinline__ void tfk_cr_fwd_chunk(const TfLevelArgs& a, const TfCrChunk<BB>& ch, int tid,
+                                                 TfCrSolveLds<BB>& sh, const TfCrIo<BB>& io,
+                                                 double* zkeep = nullptr) {
     typedef TfCr<BB> C;
     constexpr int G = C::G, B2 = BB * BB, MAXR = 4;
     static_assert(C::MAXLEN <= 16, "round count");
     const TfLayout& L = a.L;
-    const TfCrChunk<BB> ch(L, pg);
     const int grp = tid / G, g = tid % G;
     const bool row_on = g < BB;
     const int mI = ch.mI, pe = ch.pe, len = ch.len;
@@ -554,10 +578,7 @@ __device__ __forceinline__ void tfk_cr_fwd_chunk(const TfLevelArgs& a, int pg, i
     double* sYr = sh.sYr;
 
     tf_wave_sync();                                  // (the block may still be read by the previous chunk's phases)
-    {
-        const double* ys = a.rhs + (ch.nbase + ch.start) * 2 * BB;
-        for (int i = tid; i < len * 2 * BB; i += 64) sYr[2 * BB + i] = ys[i];
-    }
+    for (int i = tid; i < len * 2 * BB; i += 64) sYr[2 * BB + i] = io.ys[i];
     double Di[MAXR][BB], Lb[MAXR][BB], Ua[MAXR][BB];
 #pragma unroll
     for (int r = 0; r < MAXR; ++r) {
@@ -570,9 +591,9 @@ __device__ __forceinline__ void tfk_cr_fwd_chunk(const TfLevelArgs& a, int pg, i
         const bool vL = onB && (ends ? (nq & 1) != 0 : true);
         const bool vR = onB && (ends ? true : aa + s <= mI);
         const int k = s * (2 * grp + 1), kL = ends ? nq * s : aa - s, kR = ends ? s : aa + s;
-        const double* rk = a.crf + (ch.nbase + ch.node(onA ? k : 1)) * 5 * B2 + g * BB;
-        const double* rl = a.crf + (ch.nbase + ch.node(vL ? kL : 1)) * 5 * B2 + 4 * B2 + g * BB;
-        const double* rr = a.crf + (ch.nbase + ch.node(vR ? kR : 1)) * 5 * B2 + 3 * B2 + g * BB;
+        const double* rk = io.crf0 + ((onA ? k : 1) - 1) * 5 * B2 + g * BB;
+        const double* rl = io.crf0 + ((vL ? kL : 1) - 1) * 5 * B2 + 4 * B2 + g * BB;
+        const double* rr = io.crf0 + ((vR ? kR : 1) - 1) * 5 * B2 + 3 * B2 + g * BB;
         tf_load_row<BB>(rk, onA, Di[r]);
         tf_load_row<BB>(rl, vL, Lb[r]);
         tf_load_row<BB>(rr, vR, Ua[r]);
@@ -595,6 +616,7 @@ __device__ __forceinline__ void tfk_cr_fwd_chunk(const TfLevelArgs& a, int pg, i
                 for (int m = 0; m < BB; ++m) z = tf_fma(Di[r][m], sY[k][m], z);
                 sZ[k][g] = z;
                 a.zt[(ch.nbase + ch.node(k)) * BB + g] = z;
+                if (zkeep) zkeep[r] = z;
             }
             tf_wave_sync();
             if (grp <= nB && row_on) {
@@ -618,7 +640,7 @@ __device__ __forceinline__ void tfk_cr_fwd_chunk(const TfLevelArgs& a, int pg, i
     }
     if (a.fold_top) {
         // last level: apply the inverse of the remaining block (tfk_cr_factor_v3) and run
-        // the back-substitution rounds of this level right away (tfk_cr_bwd_chunk)
+        // the back-substitution rounds of this level right away (tfk_cr_bwd_run)
         double x = 0.0;
         if (row_on && grp == 0) {
             const int nsys = L.Ptot;
@@ -630,6 +652,7 @@ __device__ __forceinline__ void tfk_cr_fwd_chunk(const TfLevelArgs& a, int pg, i
         if (row_on && grp == 0) {
             a.topx[(int64_t)ch.e * BB + g] = x;
             a.x[(ch.nbase + ch.node(pe)) * BB + g] = x;
+            if (io.xmirror) io.xmirror[(pe - 1) * BB + g] = x;
             sY[pe][g] = x;
             sY[0][g] = ch.has_prev ? x : 0.0;
         }
@@ -642,7 +665,7 @@ __device__ __forceinline__ void tfk_cr_fwd_chunk(const TfLevelArgs& a, int pg, i
                 if (grp < nA && row_on) {
                     const int k = s * (2 * grp + 1);
                     const int kl = k - s, kr = k + s <= mI ? k + s : pe;
-                    const double* rec = a.crf + (ch.nbase + ch.node(k)) * 5 * B2 + g * BB;
+                    const double* rec = io.crf0 + (k - 1) * 5 * B2 + g * BB;
                     double xk = sZ[k][g];
 #pragma unroll
                     for (int m = 0; m < BB; ++m) {
@@ -651,49 +674,59 @@ __device__ __forceinline__ void tfk_cr_fwd_chunk(const TfLevelArgs& a, int pg, i
                     }
                     sY[k][g] = xk;
                     a.x[(ch.nbase + ch.node(k)) * BB + g] = xk;
+                    if (io.xmirror) io.xmirror[(k - 1) * BB + g] = xk;
                 }
                 tf_wave_sync();
             }
         }
     } else if (row_on && grp < 2) {
-        const int nn = grp == 0 ? ch.p : ch.pprev;
-        double* rr = a.rhsnext + ((int64_t)ch.e * a.Lnext.N + nn) * 2 * BB;
-        if (grp == 0) rr[g] = sY[pe][g]; else rr[BB + g] = sY[0][g];
+        if (grp == 0) io.next_own[g] = sY[pe][g]; else io.next_prev[g] = sY[0][g];
     }
 }
 
-// back-substitution: the separators that bound the chunk are known
+// back-substitution, in two parts: the rows of the stored reduction a lane needs (independent of
+// the right-hand side: requested as early as the caller can), then the rounds with the
+// separators that bound the chunk known
+template <int BB> struct TfCrBwdRows { double Er[4][BB], Fr[4][BB], zk[4]; };
+
 template <int BB>
-__device__ __forceinline__ void tfk_cr_bwd_chunk(const TfLevelArgs& a, int pg, int tid, TfCrSolveLds<BB>& sh) {
-    typedef TfCr<BB> C;
-    constexpr int G = C::G, B2 = BB * BB, MAXR = 4;
-    const TfLayout& L = a.L;
-    const TfCrChunk<BB> ch(L, pg);
+__device__ __forceinline__ void tfk_cr_bwd_load(const TfLevelArgs& a, const TfCrChunk<BB>& ch, int tid,
+                                                const TfCrIo<BB>& io, TfCrBwdRows<BB>& rows, bool load_z) {
+    constexpr int G = TfCr<BB>::G, B2 = BB * BB, MAXR = 4;
     const int grp = tid / G, g = tid % G;
     const bool row_on = g < BB;
-    const int mI = ch.mI, pe = ch.pe;
-    double (&sX)[TfCrSolveLds<BB>::NPOS][BB] = sh.sY;
-
-    double Er[MAXR][BB], Fr[MAXR][BB], zk[MAXR];
+    const int mI = ch.mI;
 #pragma unroll
     for (int r = 0; r < MAXR; ++r) {
         const int s = 1 << r;
         const int nA = ((mI >> r) + 1) >> 1;
         const bool on = s <= mI && grp < nA && row_on;
         const int k = on ? s * (2 * grp + 1) : 1;
-        const double* rec = a.crf + (ch.nbase + ch.node(k)) * 5 * B2 + g * BB;
-        tf_load_row<BB>(rec + 1 * B2, on, Er[r]);
-        tf_load_row<BB>(rec + 2 * B2, on, Fr[r]);
-        zk[r] = on ? a.zt[(ch.nbase + ch.node(k)) * BB + g] : 0.0;
+        const double* rec = io.crf0 + (k - 1) * 5 * B2 + g * BB;
+        tf_load_row<BB>(rec + 1 * B2, on, rows.Er[r]);
+        tf_load_row<BB>(rec + 2 * B2, on, rows.Fr[r]);
+        if (load_z) rows.zk[r] = on ? a.zt[(ch.nbase + ch.node(k)) * BB + g] : 0.0;
     }
+}
+
+// ef (optional): the E and F blocks of the chunk's nodes staged in LDS, [node][2][b][b] from the
+// chunk's first node -- then rows.Er / rows.Fr are not used (only rows.zk)
+template <int BB>
+__device__ __forceinline__ void tfk_cr_bwd_run(const TfLevelArgs& a, const TfCrChunk<BB>& ch, int tid,
+                                               TfCrSolveLds<BB>& sh, const TfCrIo<BB>& io,
+                                               const TfCrBwdRows<BB>& rows, const double* ef = nullptr) {
+    constexpr int G = TfCr<BB>::G, MAXR = 4, B2 = BB * BB;
+    const int grp = tid / G, g = tid % G;
+    const bool row_on = g < BB;
+    const int mI = ch.mI, pe = ch.pe;
+    double (&sX)[TfCrSolveLds<BB>::NPOS][BB] = sh.sY;
     tf_wave_sync();
     if (row_on && grp == 0) {
-        const double xs = a.xnext[((int64_t)ch.e * a.Lnext.N + ch.p) * BB + g];
+        const double xs = io.xn_own[g];
         sX[pe][g] = xs;
         a.x[(ch.nbase + ch.node(pe)) * BB + g] = xs;
     }
-    if (row_on && grp == 1)
-        sX[0][g] = ch.has_prev ? a.xnext[((int64_t)ch.e * a.Lnext.N + ch.pprev) * BB + g] : 0.0;
+    if (row_on && grp == 1) sX[0][g] = io.xn_prev ? io.xn_prev[g] : 0.0;
     tf_wave_sync();
 #pragma unroll
     for (int r = MAXR - 1; r >= 0; --r) {
@@ -703,11 +736,20 @@ __device__ __forceinline__ void tfk_cr_bwd_chunk(const TfLevelArgs& a, int pg, i
             if (grp < nA && row_on) {
                 const int k = s * (2 * grp + 1);
                 const int kl = k - s, kr = k + s <= mI ? k + s : pe;
-                double xk = zk[r];
+                double xk = rows.zk[r];
+                if (ef) {
+                    const double* er = ef + (k - 1) * 2 * B2 + g * BB;
 #pragma unroll
-                for (int m = 0; m < BB; ++m) {
-                    xk = tf_fma(-Er[r][m], sX[kl][m], xk);
-                    xk = tf_fma(-Fr[r][m], sX[kr][m], xk);
+                    for (int m = 0; m < BB; ++m) {
+                        xk = tf_fma(-er[m], sX[kl][m], xk);
+                        xk = tf_fma(-er[B2 + m], sX[kr][m], xk);
+                    }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < BB; ++m) {
+                        xk = tf_fma(-rows.Er[r][m], sX[kl][m], xk);
+                        xk = tf_fma(-rows.Fr[r][m], sX[kr][m], xk);
+                    }
                 }
                 sX[k][g] = xk;
                 a.x[(ch.nbase + ch.node(k)) * BB + g] = xk;
@@ -721,33 +763,93 @@ __device__ __forceinline__ void tfk_cr_bwd_chunk(const TfLevelArgs& a, int pg, i
 template <int BB>
 __device__ __forceinline__ void tfk_cr_fwd_coop(const TfLevelArgs& a) {
     __shared__ TfCrSolveLds<BB> sh;
-    tfk_cr_fwd_chunk<BB>(a, (int)blockIdx.x, (int)threadIdx.x, sh);
+    const TfCrChunk<BB> ch(a.L);
+    tfk_cr_fwd_chunk<BB>(a, ch, (int)threadIdx.x, sh, TfCrIo<BB>(a, ch));
 }
 template <int BB>
 __device__ __forceinline__ void tfk_cr_bwd_coop(const TfLevelArgs& a) {
     __shared__ TfCrSolveLds<BB> sh;
-    tfk_cr_bwd_chunk<BB>(a, (int)blockIdx.x, (int)threadIdx.x, sh);
+    const TfCrChunk<BB> ch(a.L);
+    const TfCrIo<BB> io(a, ch);
+    TfCrBwdRows<BB> rows;
+    tfk_cr_bwd_load<BB>(a, ch, (int)threadIdx.x, io, rows, true);
+    tfk_cr_bwd_run<BB>(a, ch, (int)threadIdx.x, sh, io, rows);
 }
 
 // The two smallest levels of a solve in ONE launch: level T has at most a few chunks per
 // system (8 for N = 1e6), level T+1 is the last one (one chunk, which also applies the inverse of
 // the top block and back-substitutes itself).  As three launches (forward T, forward T+1,
-// backward T) they cost 16 us of launch-to-launch latency for microseconds of work
-// (profiles/r02_solver_levels_trace.txt); here a workgroup per system gives every chunk of
-// level T a wavefront, and the hand-over between the levels is a workgroup barrier.
-#define TF_CR_TAIL_WAVES 8
+// backward T) they cost 16 us: every launch is a round trip to memory for its rows and
+// another one for what the previous launch left (profiles/r02_solver_levels_trace.txt; a first
+// fused version that kept those round trips took 18 us, profiles/r03_ab_runs.txt).  Here a
+// workgroup per system gives every chunk of level T a wavefront and pays the memory latency once:
+// at the start the workgroup requests level T+1's whole stored reduction and the blocks of level
+// T's back-substitution into LDS, and every wavefront the rows of its forward elimination; level T's share of level T+1's right-hand side, and level T+1's
+// solution, pass through LDS.
+#define TF_CR_TAIL_WAVES 8         // = the most chunks level T may have per system (one wavefront each)
+#define TF_CR_TAIL_MAXB 7          // b = 8 would need more than the 160 KB of LDS
 template <int BB>
 __device__ __forceinline__ void tfk_cr_tail_coop(const TfTailArgs& t) {
-    __shared__ TfCrSolveLds<BB> sh[TF_CR_TAIL_WAVES];
+    constexpr int B2 = BB * BB, NW = TF_CR_TAIL_WAVES, MAXLEN = TF_CR_MAXLEN;
+    __shared__ TfCrSolveLds<BB> sh[NW];
+    __shared__ double sEF[NW][MAXLEN * 2 * B2];      // level T: E and F blocks of every wavefront's chunk
+    __shared__ double sCrfTop[NW * 5 * B2];          // level T+1: stored reduction of its one chunk (<= NW nodes)
+    __shared__ double sRhsTop[NW * 2 * BB];          // ... its right-hand side records (two parts per node)
+    __shared__ double sXTop[NW * BB];                // ... its solution
     const int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63, e = (int)blockIdx.x;
     const TfLevelArgs& la = t.lv[0];
     const TfLevelArgs& lb = t.lv[1];
-    const int P = la.L.P;
-    for (int c = w; c < P; c += TF_CR_TAIL_WAVES) tfk_cr_fwd_chunk<BB>(la, e * P + c, lane, sh[w]);
-    __syncthreads();                                 // level T's share of level T+1's right-hand side is in memory
-    if (w == 0) tfk_cr_fwd_chunk<BB>(lb, e, lane, sh[0]);
-    __syncthreads();                                 // ... and level T+1's solution
-    for (int c = w; c < P; c += TF_CR_TAIL_WAVES) tfk_cr_bwd_chunk<BB>(la, e * P + c, lane, sh[w]);
+    const int P = la.L.P;                            // <= NW (host)
+    const TfCrChunk<BB> chb(lb.L, e);
+    const TfCrChunk<BB> ch(la.L, e * P + (w < P ? w : 0));
+    const bool mine = w < P;
+    TF_STAMP(la, 50);
+    {
+        const double* src = lb.crf + chb.nbase * 5 * B2;              // (one chunk: it starts at node 0 of the system)
+        for (int i = (int)threadIdx.x; i < P * 5 * B2; i += 64 * NW) sCrfTop[i] = src[i];
+    }
+    TfCrIo<BB> io(la, ch);
+    // E, F of my chunk's interior nodes (blocks 1 and 2 of a record are contiguous): needed last,
+    // requested first, and parked in registers until the forward elimination is through (an LDS
+    // store here would wait for them before the rows of the elimination are even requested)
+    constexpr int NEF = (MAXLEN * 2 * B2 + 63) / 64;
+    double ef[NEF];
+#pragma unroll
+    for (int q = 0; q < NEF; ++q) {
+        const int i = lane + 64 * q;
+        const int nd = i / (2 * B2), o = i - nd * 2 * B2;
+        ef[q] = (mine && i < ch.mI * 2 * B2) ? io.crf0[nd * 5 * B2 + B2 + o] : 0.0;
+    }
+    TfCrBwdRows<BB> rows;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rows.zk[r] = 0.0;
+    TF_STAMP(la, 51);
+    if (mine) {
+        io.next_own = sRhsTop + ch.p * 2 * BB;
+        io.next_prev = sRhsTop + ch.pprev * 2 * BB + BB;
+        tfk_cr_fwd_chunk<BB>(la, ch, lane, sh[w], io, rows.zk);
+    }
+    TF_STAMP(la, 52);
+#pragma unroll
+    for (int q = 0; q < NEF; ++q) sEF[w][lane + 64 * q < MAXLEN * 2 * B2 ? lane + 64 * q : 0] = ef[q];
+    __syncthreads();                                 // level T+1's right-hand side and stored reduction are in LDS
+    TF_STAMP(la, 53);
+    if (w == 0) {
+        TfCrIo<BB> iob(lb, chb);
+        iob.ys = sRhsTop;
+        iob.crf0 = sCrfTop;
+        iob.xmirror = sXTop;
+        tfk_cr_fwd_chunk<BB>(lb, chb, lane, sh[0], iob);
+    }
+    TF_STAMP(la, 54);
+    __syncthreads();                                 // ... and its solution
+    TF_STAMP(la, 55);
+    if (mine) {
+        io.xn_own = sXTop + ch.p * BB;
+        io.xn_prev = ch.has_prev ? sXTop + ch.pprev * BB : nullptr;
+        tfk_cr_bwd_run<BB>(la, ch, lane, sh[w], io, rows, sEF[w]);
+    }
+    TF_STAMP(la, 56);
 }
 
 // ---- top block: one group of 8 lanes inverts the b x b system of one ensemble member

@@ -166,6 +166,24 @@ __global__ void __launch_bounds__(64) tfk_l1_fwd2(TfLevelArgs a) {
         else tfk_chunk_body<TfRowsL1, -1, false, false, true, true>(a, TF_GID);
     }
 }
+// tfk_l1_fwd2 and tfk_l1_backsub_u in one launch (twisted form only): wavefront 0 of a workgroup
+// takes the down halves of 64 chunks, wavefront 1 the up halves of the same chunks.  The y of the
+// second elimination never goes to memory -- every lane keeps its half in the workgroup's LDS
+// ([direction][row][b][lane]: 49 KB for the film model), the barrier hands the rows next to the
+// middle to the other direction, and the back-substitution starts from there: 8 bytes per node and
+// variable less written, and read, per solve, and one launch less.
+__global__ void __launch_bounds__(128) tfk_l1_fwd2_backsub(TfLevelArgs a) {
+    if constexpr (TF_RESPIKE_MODEL(TF_MP, TF_NVAR)) {
+        extern __shared__ double tf_dyn_lds[];
+        const int lane = threadIdx.x & 63, dir = threadIdx.x >> 6, pg = blockIdx.x * 64 + lane;
+        double* ydn = tf_dyn_lds + lane;
+        double* yup = tf_dyn_lds + (size_t)a.ylds_rows * TF_NVAR * 64 + lane;
+        if (dir == 0) tfk_chunk_body<TfRowsL1, +1, false, false, true, true>(a, pg, ydn);
+        else tfk_chunk_body<TfRowsL1, -1, false, false, true, true>(a, pg, yup);
+        __syncthreads();
+        tfk_backsub_twist_body<TfRowsL1>(a, pg, dir, ydn, yup);
+    }
+}
 // The next level's rows.  When that level keeps records per node (cyclic reduction), the 64
 // rows of a workgroup are collected in LDS and leave as whole records: coalesced stores of
 // 3*b*b contiguous doubles per separator instead of 8 bytes per lane and instruction.
@@ -262,7 +280,7 @@ __global__ void __launch_bounds__(TF_CR_BLOCK) tfk_cr_bwd(TfLevelArgs a) {
 }
 // the last two levels of a solve: one workgroup per system (3 <= b <= 8; the host only launches it there)
 __global__ void __launch_bounds__(64 * TF_CR_TAIL_WAVES) tfk_cr_tail(TfTailArgs t) {
-    if constexpr (TF_B2 >= 3 && TF_B2 <= 8) tfk_cr_tail_coop<TF_B2>(t);
+    if constexpr (TF_B2 >= 3 && TF_B2 <= TF_CR_TAIL_MAXB) tfk_cr_tail_coop<TF_B2>(t);
 }
 
 }  // extern "C"

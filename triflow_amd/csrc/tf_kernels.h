@@ -836,8 +836,11 @@ TF_DEVICE int tf_twist_h(int mI, int enabled) {
 // those of its half (tf_twist_h); STORE_Y: the down solve walk stores yt.
 // KNOWN (tfk_l1_fwd2): the separator behind the walk is solved; the walk eliminates its half
 // of the chunk with those values on the right-hand side and stores yt.
+// ylds (KNOWN only, optional): y goes to the workgroup's LDS instead of a.yt, element (j, r) of this
+// lane's walk at ylds[(j * B + r) * 64] (tfk_l1_fwd2_backsub: the back-substitution follows in the
+// same launch).
 template <class Rows, int DIR, bool SPIKE, bool STORE_U, bool STORE_Y, bool KNOWN = false>
-TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
+TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg, double* ylds = nullptr) {
     constexpr int B = Rows::B, MP = Rows::MP, W = 2 * MP + 1;
     static_assert(!KNOWN || (!SPIKE && !STORE_U), "the re-elimination takes one right-hand side");
     constexpr bool PIV = Rows::PIVOT;             // row exchanges inside the window (B == 1)
@@ -1010,8 +1013,13 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg) {
                         }
             }
             if (STORE_Y && keep) {
+                if (KNOWN && ylds) {
 #pragma unroll
-                for (int r = 0; r < B; ++r) tf_stp(a.yt, r, L.plane, off, yn[r]);
+                    for (int r = 0; r < B; ++r) ylds[(j * B + r) * 64] = yn[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < B; ++r) tf_stp(a.yt, r, L.plane, off, yn[r]);
+                }
             }
         }
         if (HIST >= 0) {
@@ -1486,8 +1494,11 @@ TF_DEVICE bool tf_dense_solve(double (&S)[n][n], double (&g)[n]) {
 // (a = the down unknowns, b = the up unknowns: T1 a + C1 b = g1, C2 a + T2 b = g2 with unit
 // triangular T1, T2; b from the Schur complement T2 - C2 T1^-1 C1, pivoted; the same arithmetic
 // in both threads) and then stream their own half outwards like tfk_backsub_body.
+// ylds_dn / ylds_up (optional): y of the two walks comes from the workgroup's LDS (see
+// tfk_chunk_body) instead of a.yt.
 template <class Rows>
-TF_DEVICE void tfk_backsub_twist_body(const TfLevelArgs& a, int pg, int dir) {
+TF_DEVICE void tfk_backsub_twist_body(const TfLevelArgs& a, int pg, int dir,
+                                      const double* ylds_dn = nullptr, const double* ylds_up = nullptr) {
     constexpr int B = Rows::B, MP = Rows::MP, NB = MP * B;
     static_assert(!Rows::PIVOT, "the re-elimination form is for block sizes that do not exchange rows");
     const TfLayout& L = a.L;
@@ -1503,8 +1514,15 @@ TF_DEVICE void tfk_backsub_twist_body(const TfLevelArgs& a, int pg, int dir) {
     auto nat = [&](int j) { return dir == 0 ? j : mI - 1 - j; };
     auto ldU = [&](int node_nat, double (&U)[MP][B][B], double (&y)[B]) {
         const unsigned off = tf_off8(L, pg, node_nat);
+        if (ylds_dn) {
+            // the down walk numbers its nodes from the top of the chunk, the up walk from the bottom
+            const double* src = node_nat < h ? ylds_dn + node_nat * B * 64 : ylds_up + (mI - 1 - node_nat) * B * 64;
 #pragma unroll
-        for (int r = 0; r < B; ++r) y[r] = tf_ldp(a.yt, r, L.plane, off);
+            for (int r = 0; r < B; ++r) y[r] = src[r * 64];
+        } else {
+#pragma unroll
+            for (int r = 0; r < B; ++r) y[r] = tf_ldp(a.yt, r, L.plane, off);
+        }
 #pragma unroll
         for (int c = 0; c < MP; ++c)
 #pragma unroll

@@ -63,6 +63,7 @@ struct DevBuf {
         total += (int64_t)(std::max<size_t>(count, 1) * sizeof(double));
     }
     void release() { if (p) tfb::dev_free(p); p = nullptr; n = 0; }
+    void swap(DevBuf& o) { std::swap(p, o.p); std::swap(n, o.n); }
     ~DevBuf() { release(); }
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
@@ -77,6 +78,52 @@ struct Level {
     DevBuf crf, zt;        // cyclic-reduction levels (records per node, see TfLevelArgs)
     unsigned* perm = nullptr;   // ... pivot orders of the last factorisation, [nodes + systems]
     ~Level() { if (perm) tfb::dev_free(perm); }
+    Level() = default;
+    Level(const Level&) = delete;
+    Level& operator=(const Level&) = delete;
+    void swap(Level& o) {
+        std::swap(L, o.L); std::swap(B, o.B); std::swap(MP, o.MP); std::swap(cr, o.cr); std::swap(perm, o.perm);
+        DevBuf* mine[] = {&Ablk, &rhs, &x, &Ut, &Et, &yt, &tips_dn, &tips_up, &Dinv, &Unup, &crf, &zt};
+        DevBuf* theirs[] = {&o.Ablk, &o.rhs, &o.x, &o.Ut, &o.Et, &o.yt, &o.tips_dn, &o.tips_up, &o.Dinv, &o.Unup, &o.crf, &o.zt};
+        for (int i = 0; i < 12; ++i) mine[i]->swap(*theirs[i]);
+    }
+    // buffers of one level (l = 0: level 1), as planned in L / B / MP / cr
+    void alloc(size_t l, int nsys, bool l1_respike, int64_t& tot) {
+        const int64_t pl = L.plane;
+        if (cr) {
+            // records per node in natural order (TfLevelArgs)
+            const size_t nodes = (size_t)L.N * nsys;
+            Ablk.alloc(nodes * 4 * B * B, tot);
+            rhs.alloc(nodes * 2 * B, tot);
+            x.alloc(nodes * B, tot);
+            crf.alloc(nodes * 5 * B * B, tot);
+            zt.alloc(nodes * B, tot);
+            perm = (unsigned*)tfb::dev_alloc((nodes + nsys) * sizeof(unsigned));      // (zero-filled)
+            tot += (int64_t)((nodes + nsys) * sizeof(unsigned));
+            return;
+        }
+        // level 1 of a scalar model exchanges rows inside the band: U is 2*MP wide
+        const int UW = (l == 0 && B == 1) ? 2 * MP : MP;
+        Ut.alloc((size_t)UW * B * B * pl, tot);
+        if (l == 0 && l1_respike) Et.alloc(1, tot);
+        else Et.alloc((size_t)MP * B * B * pl, tot);
+        yt.alloc((size_t)B * pl, tot);
+        const size_t tipsz = (size_t)(MP * B + 2 * MP * MP * B * B) * L.Ptot;
+        tips_dn.alloc(tipsz, tot);
+        tips_up.alloc(tipsz, tot);
+        if (l > 0) {
+            Ablk.alloc((size_t)3 * B * B * pl, tot);
+            Dinv.alloc((size_t)2 * B * B * pl, tot);
+            Unup.alloc((size_t)B * B * pl, tot);
+            rhs.alloc((size_t)B * pl, tot);
+            x.alloc((size_t)B * pl, tot);
+        }
+    }
+    void alloc_top(int b2, int nsys, int64_t& tot) {
+        Ablk.alloc((size_t)4 * b2 * b2 * nsys, tot);
+        rhs.alloc((size_t)2 * b2 * nsys, tot);
+        x.alloc((size_t)b2 * nsys, tot);
+    }
 };
 
 }  // namespace
@@ -129,12 +176,34 @@ struct tf_solver {
     DevBuf topAinv;
     double factor_c = 0.0;
     bool have_factor = false, have_jac = false;
+    // Second factorisation in memory (constant matrices only, made on demand): the step-doubling
+    // controller the reference wraps around every scheme (schemes.py:33-66, simulation.py:190-197)
+    // alternates c = theta*m*dt and theta*dt, and with one set of factor buffers each change of c
+    // would throw away a factorisation that the next-but-one step needs again.  The two sets trade
+    // places (swap_slots); which one is current is part of the key of a captured step.
+    std::vector<std::unique_ptr<Level>> levels_alt;
+    Level top_alt;
+    DevBuf topAinv_alt;
+    bool alt_allocated = false;
+    int slot_id = 0;
+    struct SlotMeta {
+        double factor_c = 0.0, cf_c = 0.0;
+        bool have_factor = false, cf_valid = false, fact_checked = false, fact_needs_refine = false,
+             check_now = true, mon_this = false;
+        uint64_t cf_ver = 0;
+        int sweeps_needed = 0;
+    } meta_alt;
     bool fact_checked = false, fact_needs_refine = false;   // refine == -1 (auto)
     double last_omega = 0.0, refine_trigger = 1e-11, monitor_omega = 0.0;
     // the backward-error check is a monitor: every factorisation while the matrix is new
     // (first 4, or c changed by > 10 %), then every berr_every-th one
     int berr_every = 8;
-    int64_t n_factor = 0;
+    // ... an interval that doubles after every check that reads rounding level (a hundredth of the
+    // refinement trigger, no sweep needed), up to berr_max, and falls back to berr_every when a check
+    // or the monitor reads more or c moves (a new verdict); fixed when the caller names an interval
+    int berr_cur = 8, berr_max = 64;
+    bool berr_adaptive = true;
+    int64_t n_factor = 0, n_checks = 0, n_replans = 0;
     bool check_now = true;
     // verdicts of the checked factorisations by value of c (within 10 %): a controller that
     // alternates between two step sizes (step doubling: coarse m*dt, fine dt) does not trigger
@@ -228,13 +297,17 @@ struct tf_solver {
     // (polish() checks the first solve of an unchecked factorisation)
     bool step_graphable(double c) {
         if (reuse_ok(c)) return refine != -1 || fact_checked;
+        if (alt_ok(c)) return refine != -1 || meta_alt.fact_checked;
         return !check_due(c);
     }
+    // before a step is captured or replayed: the second set of factor buffers, if this step is
+    // the one that first needs it (an allocation cannot happen inside a capture)
+    void prepare_step(double c) { if (wants_alt(c)) ensure_alt(); }
     // will factor(c) want the synchronising backward-error check?  (then the step is not captured)
     bool check_due(double c) {
         if (refine != -1) return false;
         const Checked* like = checked_like(c);
-        return n_factor + 1 <= 4 || !like || n_factor + 1 - like->at >= berr_every;
+        return n_factor + 1 <= 4 || !like || n_factor + 1 - like->at >= berr_cur;
     }
     // refinement sweeps the solves of a factorisation with this c will run (part of the launch string)
     int sweeps_for(double c) { const Checked* like = checked_like(c); return like ? like->sweeps : -1; }
@@ -273,14 +346,15 @@ struct tf_solver {
         if (!event_pool.empty()) { auto* e = event_pool.back(); event_pool.pop_back(); return e; }
         return tfb::event_create();
     }
-    void launch(int kernel, unsigned gx, unsigned gy, unsigned block, const void* args, size_t sz) {
+    void launch(int kernel, unsigned gx, unsigned gy, unsigned block, const void* args, size_t sz,
+                unsigned lds_bytes = 0) {
         if (mode == TF_DRY) return;
         if ((timing >> kernel) & 1ull) {
             Stamp stp{kernel, get_event(), get_event()};
-            tfb::launch_timed(model->module, kernel, gx, gy, block, args, sz, stream, stp.a, stp.b);
+            tfb::launch_timed(model->module, kernel, gx, gy, block, args, sz, stream, stp.a, stp.b, lds_bytes);
             stamps.push_back(stp);
         } else {
-            tfb::launch(model->module, kernel, gx, gy, block, args, sz, stream);
+            tfb::launch(model->module, kernel, gx, gy, block, args, sz, stream, lds_bytes);
         }
     }
     void collect_timing() {
@@ -409,9 +483,16 @@ struct tf_solver {
 
     // y = cF*F + cA*(J @ sum_t vc_t vx_t): stage right-hand side of a ROW scheme in one pass
     // (every monitor_every-th factorisation: the magnitudes make the pass 40 % slower)
+    bool mon_this = false;         // the factorisation in memory is one the monitor samples (set by factor())
     bool monitor_due(const double* monitor_rhs, int nterms, const double* vc) const {
-        return monitor_rhs && nterms == 1 && vc[0] != 0.0 && refine < 0 && !reused &&
-               (refine == -2 || n_factor % monitor_every == monitor_every / 2);
+        return monitor_rhs && nterms == 1 && vc[0] != 0.0 && refine < 0 && !reused && mon_this;
+    }
+    // will the next factorisation (with this c) be sampled by the monitor?  Halfway between two
+    // explicit checks; refine = -2: every one
+    bool will_monitor(double c) {
+        if (refine == -2) return true;
+        const Checked* like = checked_like(c);
+        return refine == -1 && !check_due(c) && like && n_factor + 1 - like->at == berr_cur / 2;
     }
     // Right-hand side of Rosenbrock stage i >= 1,  dt*F(U + sum_j alpha_ij k_j) + dt*(J @ sum_j gamma_ij k_j):
     // one pass (tfk_sweep_f_stage_rhs) that evaluates F from the window and multiplies J by the other
@@ -425,8 +506,51 @@ struct tf_solver {
     double cf_c = 0.0;
     uint64_t par_ver = 0, cf_ver = 0;
     bool reuse_ok(double c) const { return jconst && cf_valid && have_jac && cf_c == c && cf_ver == par_ver; }
+    bool alt_ok(double c) const {
+        return jconst && alt_allocated && meta_alt.cf_valid && have_jac && meta_alt.cf_c == c && meta_alt.cf_ver == par_ver;
+    }
+    // the factorisation in memory is valid for another c: the next one goes to the other set
+    bool wants_alt(double c) const {
+        return jconst && two_slots && !reuse_ok(c) && !alt_ok(c) && cf_valid && have_jac && cf_ver == par_ver;
+    }
+    bool two_slots = true;         // (TRIFLOW_TWO_FACTORS=0: A/B runs)
+    void ensure_alt() {
+        if (alt_allocated) return;
+        for (size_t l = 0; l < levels.size(); ++l) {
+            std::unique_ptr<Level> lv(new Level());
+            lv->L = levels[l]->L; lv->B = levels[l]->B; lv->MP = levels[l]->MP; lv->cr = levels[l]->cr;
+            lv->alloc(l, nsys, l1_respike, bytes);
+            levels_alt.push_back(std::move(lv));
+        }
+        top_alt.L = top.L; top_alt.B = top.B; top_alt.MP = top.MP;
+        top_alt.alloc_top(top.B, nsys, bytes);
+        topAinv_alt.alloc((size_t)top.B * top.B * nsys, bytes);
+        alt_allocated = true;
+    }
+    void swap_slots() {
+        levels.swap(levels_alt);
+        top.swap(top_alt);
+        topAinv.swap(topAinv_alt);
+        SlotMeta cur;
+        cur.factor_c = factor_c; cur.cf_c = cf_c; cur.have_factor = have_factor; cur.cf_valid = cf_valid;
+        cur.fact_checked = fact_checked; cur.fact_needs_refine = fact_needs_refine; cur.check_now = check_now;
+        cur.mon_this = mon_this; cur.cf_ver = cf_ver; cur.sweeps_needed = sweeps_needed;
+        factor_c = meta_alt.factor_c; cf_c = meta_alt.cf_c; have_factor = meta_alt.have_factor; cf_valid = meta_alt.cf_valid;
+        fact_checked = meta_alt.fact_checked; fact_needs_refine = meta_alt.fact_needs_refine; check_now = meta_alt.check_now;
+        mon_this = meta_alt.mon_this; cf_ver = meta_alt.cf_ver; sweeps_needed = meta_alt.sweeps_needed;
+        meta_alt = cur;
+        slot_id ^= 1;
+    }
+    // which set of factor buffers a step with this c will run on, and whether it reuses what is there
+    // (both go into the key of a captured step)
+    std::string slot_key(double c) const {
+        const bool reuse = reuse_ok(c) || alt_ok(c);
+        const int slot = reuse_ok(c) ? slot_id : ((alt_ok(c) || wants_alt(c)) ? slot_id ^ 1 : slot_id);
+        return std::string(reuse ? "|u" : "|f") + (slot ? "1" : "0");
+    }
     bool l1_respike = false;       // level-1 spike response not stored (tf_args.h, TF_RESPIKE_*)
     int l1_twist = -1;             // -1: by the number of chunks; 0 / 1: TRIFLOW_L1_TWIST (tests, A/B runs)
+    bool l1_fuse_backsub = true;   // twisted form: tfk_l1_fwd2_backsub (TRIFLOW_L1_FUSE_BACKSUB=0: two launches)
     void stage_rhs(const double* Uin, int nterms, const double* const* ks, const double* ac,
                    const double* gc, double dt, double* y, const double* monitor_rhs) {
         if (!fuse_stage || monitor_due(monitor_rhs, nterms, gc)) {
@@ -538,7 +662,8 @@ struct tf_solver {
         ++n_factor;
         cf_valid = jconst; cf_c = c; cf_ver = par_ver;
         const Checked* like = checked_like(c);
-        check_now = refine == -1 && (n_factor <= 4 || !like || n_factor - like->at >= berr_every);
+        check_now = refine == -1 && (n_factor <= 4 || !like || n_factor - like->at >= berr_cur);
+        mon_this = refine == -2 || (refine == -1 && !check_now && like && n_factor - like->at == berr_cur / 2);
         if (check_now) { fact_checked = false; fact_needs_refine = false; sweeps_needed = 0; }
         else if (like) { sweeps_needed = like->sweeps; fact_needs_refine = sweeps_needed > 0; }
         // (between checks the verdict of the last checked factorisation with such a c stands)
@@ -553,6 +678,8 @@ struct tf_solver {
     // (schemes.py:148-149, 557: the reference factorises in every step)
     void factor_step(double c, const double* rhs1, double* x1) {
         reused = reuse_ok(c);
+        if (!reused && alt_ok(c)) { swap_slots(); reused = true; }
+        else if (wants_alt(c)) { ensure_alt(); swap_slots(); }        // (allocated before any capture: prepare_step)
         if (!reused) { factor(c, rhs1, x1); return; }
         have_factor = true;                          // (the sweep of this step reset it)
         solve(rhs1, x1);
@@ -566,6 +693,18 @@ struct tf_solver {
             if (l == 0) {
                 // (twisted: grid.y = 2, the down and the up half of every chunk, tf_twist_h)
                 const unsigned gy = a.twist ? 2u : 1u;
+                if (l1_respike && a.twist && l1_fuse_backsub && tfb::is_device_build()) {
+                    // both in one launch, y in LDS: rows = the longer half of the longest chunk
+                    // (tf_twist_h of tf_kernels.h: chunks too short to split, and wide blocks, stay one-sided)
+                    auto half = [&](int mI) { return (spec.mp * spec.nvar <= 6 && mI >= 4 * spec.mp) ? (mI + 1) / 2 : mI; };
+                    const int mI_max = a.L.M - spec.mp;
+                    a.ylds_rows = std::max(half(mI_max), a.L.rem > 0 ? half(mI_max - 1) : 0);
+                    const size_t lds = (size_t)2 * a.ylds_rows * spec.nvar * 64 * sizeof(double);
+                    if (lds <= 64u * 1024u) {
+                        launch(TFK_L1_FWD2_BACKSUB, cdiv(a.L.Ptot, 64), 1, 128, &a, sizeof(a), (unsigned)lds);
+                        continue;
+                    }
+                }
                 if (l1_respike) launch(TFK_L1_FWD2, cdiv(a.L.Ptot, 64), gy, 64, &a, sizeof(a));
                 launch(l1_respike ? TFK_L1_BACKSUB_U : TFK_L1_BACKSUB, cdiv(a.L.Ptot, 64), gy, 64, &a, sizeof(a));
             }
@@ -574,12 +713,12 @@ struct tf_solver {
         }
     }
     // The two last levels of a solve go in one launch (tfk_cr_tail) when both are cyclic-reduction
-    // levels of 3 <= b <= 8 and the first of them has a handful of chunks per system
+    // levels of 3 <= b <= 7 and the first of them has at most 8 chunks per system
     bool cr_tail = true;           // (TRIFLOW_CR_TAIL=0: A/B runs)
     bool tail_ok() const {
         const size_t n = levels.size();
-        return cr_tail && n >= 3 && top.B >= 3 && top.B <= 8 && levels[n - 1]->cr && levels[n - 2]->cr &&
-               levels[n - 1]->L.P == 1 && levels[n - 2]->L.P <= 16;
+        return cr_tail && n >= 3 && top.B >= 3 && top.B <= 7 && levels[n - 1]->cr && levels[n - 2]->cr &&
+               levels[n - 1]->L.P == 1 && levels[n - 2]->L.P <= 8;      // TF_CR_TAIL_MAXB, TF_CR_TAIL_WAVES
     }
     void solve_once(const double* rhs1, double* x1) {
         const bool tail = tail_ok();
@@ -614,6 +753,7 @@ struct tf_solver {
     // componentwise (Oettli-Prager) backward error
     //   max_i |b - A x|_i / (|x| + |c J||x| + |b|)_i
     double backward_error(const double* rhs1, const double* x1) {
+        ++n_checks;
         tfb::memset0(red.p, sizeof(double), stream);
         TfBerrArgs a;
         a.L = L1; a.Jv = Jv.p; a.x = x1; a.rhs = rhs1; a.c = factor_c; a.red = red.p;
@@ -661,6 +801,9 @@ struct tf_solver {
                     }
                 }
                 fact_needs_refine = sweeps_needed > 0;
+                if (berr_adaptive)
+                    berr_cur = (sweeps_needed == 0 && last_omega <= 0.01 * refine_trigger)
+                        ? std::min(2 * berr_cur, std::max(berr_max, berr_every)) : berr_every;
                 if (!(last_omega <= 1e-6)) unstable = true;
                 if (Checked* e = checked_like(factor_c)) { e->c = factor_c; e->sweeps = sweeps_needed; e->at = n_factor; }
                 else {
@@ -678,7 +821,6 @@ struct tf_solver {
     // synchronisation); with refine = -2 every step does.  The worst value since the last look is
     // read here, at the synchronising calls.
     bool monitored = false;
-    int monitor_every = 8;     // ... halfway between two explicit checks (berr_every)
     void check_status() {
         int flag = 0;
         tfb::d2h(&flag, status, sizeof(int), stream);
@@ -691,6 +833,7 @@ struct tf_solver {
                 // some factorisation since the last check lost accuracy that the checked ones had
                 // not: forget the verdicts, the next factorisation is checked (and refined)
                 checked.clear();
+                berr_cur = berr_every;
                 monitor_omega = worst;
                 if (!(worst <= 1e-6)) { last_omega = worst; unstable = true; }
             }
@@ -761,7 +904,7 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
     // 0 = never, n > 0 = fixed sweeps, -1 = auto (explicit checks + the in-pass monitor of the
     // Rosenbrock steps), -2 = the monitor only (no synchronising check at all)
     s->refine = opts ? opts->refine : -1;
-    if (opts && opts->berr_every > 0) s->berr_every = opts->berr_every;
+    if (opts && opts->berr_every > 0) { s->berr_every = s->berr_cur = opts->berr_every; s->berr_adaptive = false; }
     if (opts && opts->device >= 0) tfb::set_device(opts->device);
     mup = std::max(mup, 2);
     s->stream = tfb::stream_create();
@@ -769,6 +912,8 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
     if (const char* v = getenv("TRIFLOW_GRAPHS")) s->graphs_on = tfb::graphs_supported() && atoi(v) != 0;
     if (const char* v = getenv("TRIFLOW_FUSE_STAGE")) s->fuse_stage = atoi(v) != 0;      // A/B runs
     if (const char* v = getenv("TRIFLOW_CR_TAIL")) s->cr_tail = atoi(v) != 0;
+    if (const char* v = getenv("TRIFLOW_L1_FUSE_BACKSUB")) s->l1_fuse_backsub = atoi(v) != 0;
+    if (const char* v = getenv("TRIFLOW_TWO_FACTORS")) s->two_slots = atoi(v) != 0;
     s->l1_respike = TF_RESPIKE_MODEL(sp.mp, sp.nvar) && (int64_t)N * nsys >= TF_RESPIKE_MIN_NODES;
     if (const char* v = getenv("TRIFLOW_L1_TWIST")) s->l1_twist = atoi(v) != 0 ? 1 : 0;
     if (const char* v = getenv("TRIFLOW_L1_RESPIKE"))                                   // A/B runs, tests
@@ -844,42 +989,8 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
     for (int i = 0; i < TF_MAX_TERMS; ++i) s->K[i].alloc(i < 6 ? (size_t)sp.nvar * plane : 1, tot);
     s->red.alloc(8, tot);
     s->status = (int*)tfb::dev_alloc(sizeof(int));
-    for (size_t l = 0; l < s->levels.size(); ++l) {
-        Level& lv = *s->levels[l];
-        const int B = lv.B, MP = lv.MP;
-        const int64_t pl = lv.L.plane;
-        if (lv.cr) {
-            // records per node in natural order (TfLevelArgs)
-            const size_t nodes = (size_t)lv.L.N * nsys;
-            lv.Ablk.alloc(nodes * 4 * B * B, tot);
-            lv.rhs.alloc(nodes * 2 * B, tot);
-            lv.x.alloc(nodes * B, tot);
-            lv.crf.alloc(nodes * 5 * B * B, tot);
-            lv.zt.alloc(nodes * B, tot);
-            lv.perm = (unsigned*)tfb::dev_alloc((nodes + nsys) * sizeof(unsigned));      // (zero-filled)
-            tot += (int64_t)((nodes + nsys) * sizeof(unsigned));
-            continue;
-        }
-        // level 1 of a scalar model exchanges rows inside the band: U is 2*MP wide
-        const int UW = (l == 0 && B == 1) ? 2 * MP : MP;
-        lv.Ut.alloc((size_t)UW * B * B * pl, tot);
-        if (l == 0 && s->l1_respike) lv.Et.alloc(1, tot);
-        else lv.Et.alloc((size_t)MP * B * B * pl, tot);
-        lv.yt.alloc((size_t)B * pl, tot);
-        const size_t tipsz = (size_t)(MP * B + 2 * MP * MP * B * B) * lv.L.Ptot;
-        lv.tips_dn.alloc(tipsz, tot);
-        lv.tips_up.alloc(tipsz, tot);
-        if (l > 0) {
-            lv.Ablk.alloc((size_t)3 * B * B * pl, tot);
-            lv.Dinv.alloc((size_t)2 * B * B * pl, tot);
-            lv.Unup.alloc((size_t)B * B * pl, tot);
-            lv.rhs.alloc((size_t)B * pl, tot);
-            lv.x.alloc((size_t)B * pl, tot);
-        }
-    }
-    s->top.Ablk.alloc((size_t)4 * b2 * b2 * nsys, tot);
-    s->top.rhs.alloc((size_t)2 * b2 * nsys, tot);
-    s->top.x.alloc((size_t)b2 * nsys, tot);
+    for (size_t l = 0; l < s->levels.size(); ++l) s->levels[l]->alloc(l, nsys, s->l1_respike, tot);
+    s->top.alloc_top(b2, nsys, tot);
     s->topAinv.alloc((size_t)b2 * b2 * nsys, tot);
     *out = s.release();
     TF_API_END
@@ -974,6 +1085,7 @@ int tf_set_constant_jacobian(tf_solver* s, int32_t on) {
     require(s, "null solver");
     s->jconst = on != 0;
     s->cf_valid = false;
+    s->meta_alt.cf_valid = false;
     s->drop_graphs();
     TF_API_END
 }
@@ -1264,7 +1376,8 @@ int tf_step_theta(tf_solver* s, int32_t src, int32_t dst, double dt, double thet
     require(s, "null solver");
     const std::string key = "T|" + std::to_string(src) + ">" + std::to_string(dst) + "|" + bits_of(dt) + "|" +
         bits_of(theta) + "|" + std::to_string(s->ndir) + "|" + std::to_string(s->sweeps_for(theta * dt)) + "|" + std::to_string(s->refine) +
-        (s->reuse_ok(theta * dt) ? "|u" : "|f");      // (a step that reuses the factorisation is another string of launches)
+        s->slot_key(theta * dt);      // (a step that reuses a factorisation is another string of launches, on its buffers)
+    s->prepare_step(theta * dt);
     s->run_graphed(key, s->step_graphable(theta * dt), [&] { step_theta(s, src, dst, dt, theta); });
     TF_API_END
 }
@@ -1278,7 +1391,8 @@ int tf_step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns,
     std::string key = "R|" + std::to_string(src) + ">" + std::to_string(dst) + "|" + bits_of(dt) + "|" +
         std::to_string(ns) + "|" + std::to_string(hook_after) + "|" + std::to_string(s->ndir) + "|" +
         std::to_string(s->sweeps_for(gamma[0] * dt)) + "|" + std::to_string(s->refine) + "|" + (b_pred && err_out ? "e" : "-") +
-        (s->reuse_ok(gamma[0] * dt) ? "u" : ((s->n_factor + 1) % s->monitor_every == s->monitor_every / 2 ? "m" : "-"));
+        (s->will_monitor(gamma[0] * dt) ? "m" : "-") + s->slot_key(gamma[0] * dt);
+    s->prepare_step(gamma[0] * dt);
     for (int i = 0; i < ns * ns; ++i) key += bits_of(alpha[i]) + bits_of(gamma[i]);
     for (int i = 0; i < ns; ++i) key += bits_of(b[i]) + (b_pred ? bits_of(b_pred[i]) : std::string("-"));
     s->run_graphed(key, s->step_graphable(gamma[0] * dt), [&] {
@@ -1431,6 +1545,15 @@ int tf_monitor_error(tf_solver* s, double* worst) {
     require(s && worst, "null argument");
     *worst = 0.0;
     if (s->monitored) tfb::d2h(worst, s->red.p + 4, sizeof(double), s->stream);
+    TF_API_END
+}
+
+int tf_solver_counters(tf_solver* s, int64_t* factorisations, int64_t* checks, int64_t* replans) {
+    TF_API_BEGIN
+    require(s, "null solver");
+    if (factorisations) *factorisations = s->n_factor;
+    if (checks) *checks = s->n_checks;
+    if (replans) *replans = s->n_replans;
     TF_API_END
 }
 
