@@ -40,11 +40,9 @@ def test_FJ_bitexact_ragged(name, N):
 def test_linear_solve_small(name):
     plans = [dict(m1=4, m_upper=2), dict(m1=7, m_upper=3), dict(m1=32, m_upper=8),
              dict(m1=10 ** 6), dict()]
-    if name in ("kdv", "kuramoto"):
-        # dispersion-dominated scalar equations: block elimination does not pivot
-        # across nodes, so very short chunks lose accuracy ("solver
-        # limits"); the default plan plus automatic refinement is what is supported
-        plans = [dict(m1=32, m_upper=8), dict()]
+    # (kdv, kuramoto: dispersion-dominated scalar equations, on which elimination without pivoting
+    # across separators loses accuracy with very short chunks -- those plans are rescued by the
+    # library on longer chunks, DESIGN.md "solver limits"; every plan has to agree with SuperLU)
     # wide4: fourth derivatives at dx = 5e-3, cond(A) ~ 1e9 for both solvers
     tol = {"wide4": 1e-7}.get(name, 1e-9)
     pc.check_linear_solve(name, HIP, 203, plans, tol=tol)
@@ -456,8 +454,8 @@ def test_fused_stage_rhs():
     pc.check_fused_stage_rhs(HIP)
 
 
-def test_unstable_factorisation_is_loud():
-    pc.check_unstable_factorisation_is_loud(HIP)
+def test_unstable_factorisation_recovers():
+    pc.check_unstable_factorisation_recovers(HIP)
 
 
 def test_ensemble_equals_single_members():

@@ -545,24 +545,29 @@ template <int BB> struct TfCrIo {
     const double* crf0;      // stored reduction, record of the chunk's first node ([node][5][b][b])
     double* next_own;        // forward: part 0 of next-level node p   [b]   (not with fold_top)
     double* next_prev;       //          part 1 of next-level node p-1 [b]
-    double* xmirror;         // fold_top: a second copy of the solution [node][b] (or NULL)
-    const double* xn_own;    // backward: solution of next-level node p [b], of node p-1 (NULL: none)
+    // (flags, not null tests: a test of an LDS pointer against NULL trips hipcc 7.2 for b = 7,
+    // "Illegal instruction detected: V_CMP_NE_U32 0, $src_shared_base")
+    double* xmirror;         // fold_top: a second copy of the solution [node][b], if has_mirror
+    bool has_mirror;
+    const double* xn_own;    // backward: solution of next-level node p [b], of node p-1 if has_xprev
     const double* xn_prev;
+    bool has_xprev;
     __device__ __forceinline__ TfCrIo(const TfLevelArgs& a, const TfCrChunk<BB>& ch) {
         ys = a.rhs + (ch.nbase + ch.start) * 2 * BB;
         crf0 = a.crf + (ch.nbase + ch.start) * 5 * BB * BB;
         next_own = a.rhsnext ? a.rhsnext + ((int64_t)ch.e * a.Lnext.N + ch.p) * 2 * BB : nullptr;
         next_prev = a.rhsnext ? a.rhsnext + ((int64_t)ch.e * a.Lnext.N + ch.pprev) * 2 * BB + BB : nullptr;
-        xmirror = nullptr;
+        xmirror = nullptr; has_mirror = false;
         xn_own = a.xnext ? a.xnext + ((int64_t)ch.e * a.Lnext.N + ch.p) * BB : nullptr;
-        xn_prev = (a.xnext && ch.has_prev) ? a.xnext + ((int64_t)ch.e * a.Lnext.N + ch.pprev) * BB : nullptr;
+        xn_prev = a.xnext ? a.xnext + ((int64_t)ch.e * a.Lnext.N + ch.pprev) * BB : nullptr;
+        has_xprev = ch.has_prev;
     }
 };
 
 // forward elimination of the right-hand side through chunk `ch`; tid = lane of its wavefront.
 // zkeep[r] (optional): z of this lane's task of round r stays in a register for the
 // back-substitution of the same launch.
-template <int BB>
+template <int BB, bool KEEPZ = false>
 __device__ __forceinline__ void tfk_cr_fwd_chunk(const TfLevelArgs& a, const TfCrChunk<BB>& ch, int tid,
                                                  TfCrSolveLds<BB>& sh, const TfCrIo<BB>& io,
                                                  double* zkeep = nullptr) {
@@ -616,7 +621,7 @@ __device__ __forceinline__ void tfk_cr_fwd_chunk(const TfLevelArgs& a, const TfC
                 for (int m = 0; m < BB; ++m) z = tf_fma(Di[r][m], sY[k][m], z);
                 sZ[k][g] = z;
                 a.zt[(ch.nbase + ch.node(k)) * BB + g] = z;
-                if (zkeep) zkeep[r] = z;
+                if (KEEPZ) zkeep[r] = z;
             }
             tf_wave_sync();
             if (grp <= nB && row_on) {
@@ -652,7 +657,7 @@ __device__ __forceinline__ void tfk_cr_fwd_chunk(const TfLevelArgs& a, const TfC
         if (row_on && grp == 0) {
             a.topx[(int64_t)ch.e * BB + g] = x;
             a.x[(ch.nbase + ch.node(pe)) * BB + g] = x;
-            if (io.xmirror) io.xmirror[(pe - 1) * BB + g] = x;
+            if (io.has_mirror) io.xmirror[(pe - 1) * BB + g] = x;
             sY[pe][g] = x;
             sY[0][g] = ch.has_prev ? x : 0.0;
         }
@@ -674,7 +679,7 @@ __device__ __forceinline__ void tfk_cr_fwd_chunk(const TfLevelArgs& a, const TfC
                     }
                     sY[k][g] = xk;
                     a.x[(ch.nbase + ch.node(k)) * BB + g] = xk;
-                    if (io.xmirror) io.xmirror[(k - 1) * BB + g] = xk;
+                    if (io.has_mirror) io.xmirror[(k - 1) * BB + g] = xk;
                 }
                 tf_wave_sync();
             }
@@ -711,7 +716,7 @@ __device__ __forceinline__ void tfk_cr_bwd_load(const TfLevelArgs& a, const TfCr
 
 // ef (optional): the E and F blocks of the chunk's nodes staged in LDS, [node][2][b][b] from the
 // chunk's first node -- then rows.Er / rows.Fr are not used (only rows.zk)
-template <int BB>
+template <int BB, bool USE_EF = false>
 __device__ __forceinline__ void tfk_cr_bwd_run(const TfLevelArgs& a, const TfCrChunk<BB>& ch, int tid,
                                                TfCrSolveLds<BB>& sh, const TfCrIo<BB>& io,
                                                const TfCrBwdRows<BB>& rows, const double* ef = nullptr) {
@@ -726,7 +731,7 @@ __device__ __forceinline__ void tfk_cr_bwd_run(const TfLevelArgs& a, const TfCrC
         sX[pe][g] = xs;
         a.x[(ch.nbase + ch.node(pe)) * BB + g] = xs;
     }
-    if (row_on && grp == 1) sX[0][g] = io.xn_prev ? io.xn_prev[g] : 0.0;
+    if (row_on && grp == 1) sX[0][g] = io.has_xprev ? io.xn_prev[g] : 0.0;
     tf_wave_sync();
 #pragma unroll
     for (int r = MAXR - 1; r >= 0; --r) {
@@ -737,7 +742,7 @@ __device__ __forceinline__ void tfk_cr_bwd_run(const TfLevelArgs& a, const TfCrC
                 const int k = s * (2 * grp + 1);
                 const int kl = k - s, kr = k + s <= mI ? k + s : pe;
                 double xk = rows.zk[r];
-                if (ef) {
+                if (USE_EF) {
                     const double* er = ef + (k - 1) * 2 * B2 + g * BB;
 #pragma unroll
                     for (int m = 0; m < BB; ++m) {
@@ -787,7 +792,7 @@ __device__ __forceinline__ void tfk_cr_bwd_coop(const TfLevelArgs& a) {
 // T's back-substitution into LDS, and every wavefront the rows of its forward elimination; level T's share of level T+1's right-hand side, and level T+1's
 // solution, pass through LDS.
 #define TF_CR_TAIL_WAVES 8         // = the most chunks level T may have per system (one wavefront each)
-#define TF_CR_TAIL_MAXB 7          // b = 8 would need more than the 160 KB of LDS
+#define TF_CR_TAIL_MAXB 6          // (b = 7 spills and trips a hipcc 7.2 code-generation error; b = 8 exceeds the LDS)
 template <int BB>
 __device__ __forceinline__ void tfk_cr_tail_coop(const TfTailArgs& t) {
     constexpr int B2 = BB * BB, NW = TF_CR_TAIL_WAVES, MAXLEN = TF_CR_MAXLEN;
@@ -804,9 +809,17 @@ __device__ __forceinline__ void tfk_cr_tail_coop(const TfTailArgs& t) {
     const TfCrChunk<BB> ch(la.L, e * P + (w < P ? w : 0));
     const bool mine = w < P;
     TF_STAMP(la, 50);
+    // level T+1's stored reduction: requested now, put into LDS once every other request of this
+    // wavefront is on its way (the store waits for the data)
+    constexpr int NTOP = (NW * 5 * B2 + 64 * NW - 1) / (64 * NW);
+    double topv[NTOP];
     {
         const double* src = lb.crf + chb.nbase * 5 * B2;              // (one chunk: it starts at node 0 of the system)
-        for (int i = (int)threadIdx.x; i < P * 5 * B2; i += 64 * NW) sCrfTop[i] = src[i];
+#pragma unroll
+        for (int q = 0; q < NTOP; ++q) {
+            const int i = (int)threadIdx.x + 64 * NW * q;
+            topv[q] = i < P * 5 * B2 ? src[i] : 0.0;
+        }
     }
     TfCrIo<BB> io(la, ch);
     // E, F of my chunk's interior nodes (blocks 1 and 2 of a record are contiguous): needed last,
@@ -827,18 +840,23 @@ __device__ __forceinline__ void tfk_cr_tail_coop(const TfTailArgs& t) {
     if (mine) {
         io.next_own = sRhsTop + ch.p * 2 * BB;
         io.next_prev = sRhsTop + ch.pprev * 2 * BB + BB;
-        tfk_cr_fwd_chunk<BB>(la, ch, lane, sh[w], io, rows.zk);
+        tfk_cr_fwd_chunk<BB, true>(la, ch, lane, sh[w], io, rows.zk);
     }
     TF_STAMP(la, 52);
 #pragma unroll
     for (int q = 0; q < NEF; ++q) sEF[w][lane + 64 * q < MAXLEN * 2 * B2 ? lane + 64 * q : 0] = ef[q];
+#pragma unroll
+    for (int q = 0; q < NTOP; ++q) {
+        const int i = (int)threadIdx.x + 64 * NW * q;
+        if (i < NW * 5 * B2) sCrfTop[i] = topv[q];
+    }
     __syncthreads();                                 // level T+1's right-hand side and stored reduction are in LDS
     TF_STAMP(la, 53);
     if (w == 0) {
         TfCrIo<BB> iob(lb, chb);
         iob.ys = sRhsTop;
         iob.crf0 = sCrfTop;
-        iob.xmirror = sXTop;
+        iob.xmirror = sXTop; iob.has_mirror = true;
         tfk_cr_fwd_chunk<BB>(lb, chb, lane, sh[0], iob);
     }
     TF_STAMP(la, 54);
@@ -846,8 +864,8 @@ __device__ __forceinline__ void tfk_cr_tail_coop(const TfTailArgs& t) {
     TF_STAMP(la, 55);
     if (mine) {
         io.xn_own = sXTop + ch.p * BB;
-        io.xn_prev = ch.has_prev ? sXTop + ch.pprev * BB : nullptr;
-        tfk_cr_bwd_run<BB>(la, ch, lane, sh[w], io, rows, sEF[w]);
+        io.xn_prev = sXTop + ch.pprev * BB;
+        tfk_cr_bwd_run<BB, true>(la, ch, lane, sh[w], io, rows, sEF[w]);
     }
     TF_STAMP(la, 56);
 }

@@ -178,10 +178,10 @@ __global__ void __launch_bounds__(128) tfk_l1_fwd2_backsub(TfLevelArgs a) {
         const int lane = threadIdx.x & 63, dir = threadIdx.x >> 6, pg = blockIdx.x * 64 + lane;
         double* ydn = tf_dyn_lds + lane;
         double* yup = tf_dyn_lds + (size_t)a.ylds_rows * TF_NVAR * 64 + lane;
-        if (dir == 0) tfk_chunk_body<TfRowsL1, +1, false, false, true, true>(a, pg, ydn);
-        else tfk_chunk_body<TfRowsL1, -1, false, false, true, true>(a, pg, yup);
+        if (dir == 0) tfk_chunk_body<TfRowsL1, +1, false, false, true, true, true>(a, pg, ydn);
+        else tfk_chunk_body<TfRowsL1, -1, false, false, true, true, true>(a, pg, yup);
         __syncthreads();
-        tfk_backsub_twist_body<TfRowsL1>(a, pg, dir, ydn, yup);
+        tfk_backsub_twist_body<TfRowsL1, true>(a, pg, dir, ydn, yup);
     }
 }
 // The next level's rows.  When that level keeps records per node (cyclic reduction), the 64

@@ -839,7 +839,9 @@ TF_DEVICE int tf_twist_h(int mI, int enabled) {
 // ylds (KNOWN only, optional): y goes to the workgroup's LDS instead of a.yt, element (j, r) of this
 // lane's walk at ylds[(j * B + r) * 64] (tfk_l1_fwd2_backsub: the back-substitution follows in the
 // same launch).
-template <class Rows, int DIR, bool SPIKE, bool STORE_U, bool STORE_Y, bool KNOWN = false>
+// (YLDS is a flag, not a null test of the pointer: testing an LDS pointer against NULL trips
+// hipcc 7.2 on some models, "Illegal instruction detected: V_CMP_NE_U32 0, $src_shared_base")
+template <class Rows, int DIR, bool SPIKE, bool STORE_U, bool STORE_Y, bool KNOWN = false, bool YLDS = false>
 TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg, double* ylds = nullptr) {
     constexpr int B = Rows::B, MP = Rows::MP, W = 2 * MP + 1;
     static_assert(!KNOWN || (!SPIKE && !STORE_U), "the re-elimination takes one right-hand side");
@@ -1013,7 +1015,7 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg, double* ylds = nullp
                         }
             }
             if (STORE_Y && keep) {
-                if (KNOWN && ylds) {
+                if (KNOWN && YLDS) {
 #pragma unroll
                     for (int r = 0; r < B; ++r) ylds[(j * B + r) * 64] = yn[r];
                 } else {
@@ -1496,7 +1498,7 @@ TF_DEVICE bool tf_dense_solve(double (&S)[n][n], double (&g)[n]) {
 // in both threads) and then stream their own half outwards like tfk_backsub_body.
 // ylds_dn / ylds_up (optional): y of the two walks comes from the workgroup's LDS (see
 // tfk_chunk_body) instead of a.yt.
-template <class Rows>
+template <class Rows, bool YLDS = false>
 TF_DEVICE void tfk_backsub_twist_body(const TfLevelArgs& a, int pg, int dir,
                                       const double* ylds_dn = nullptr, const double* ylds_up = nullptr) {
     constexpr int B = Rows::B, MP = Rows::MP, NB = MP * B;
@@ -1514,7 +1516,7 @@ TF_DEVICE void tfk_backsub_twist_body(const TfLevelArgs& a, int pg, int dir,
     auto nat = [&](int j) { return dir == 0 ? j : mI - 1 - j; };
     auto ldU = [&](int node_nat, double (&U)[MP][B][B], double (&y)[B]) {
         const unsigned off = tf_off8(L, pg, node_nat);
-        if (ylds_dn) {
+        if (YLDS) {
             // the down walk numbers its nodes from the top of the chunk, the up walk from the bottom
             const double* src = node_nat < h ? ylds_dn + node_nat * B * 64 : ylds_up + (mI - 1 - node_nat) * B * 64;
 #pragma unroll

@@ -189,7 +189,7 @@ struct tf_solver {
     struct SlotMeta {
         double factor_c = 0.0, cf_c = 0.0;
         bool have_factor = false, cf_valid = false, fact_checked = false, fact_needs_refine = false,
-             check_now = true, mon_this = false;
+             check_now = true, mon_this = false, delegated = false;
         uint64_t cf_ver = 0;
         int sweeps_needed = 0;
     } meta_alt;
@@ -208,7 +208,7 @@ struct tf_solver {
     // verdicts of the checked factorisations by value of c (within 10 %): a controller that
     // alternates between two step sizes (step doubling: coarse m*dt, fine dt) does not trigger
     // a synchronising check at every switch
-    struct Checked { double c; int sweeps; int64_t at; };
+    struct Checked { double c; int sweeps; int64_t at; bool replan; };
     std::vector<Checked> checked;
     Checked* checked_like(double c) {
         for (auto& e : checked)
@@ -296,6 +296,7 @@ struct tf_solver {
     // factorisation in memory reused -- none left over by a tf_factor call without a solve
     // (polish() checks the first solve of an unchecked factorisation)
     bool step_graphable(double c) {
+        if (const Checked* like = checked_like(c); like && like->replan) return false;   // (the child checks every solve)
         if (reuse_ok(c)) return refine != -1 || fact_checked;
         if (alt_ok(c)) return refine != -1 || meta_alt.fact_checked;
         return !check_due(c);
@@ -331,7 +332,8 @@ struct tf_solver {
         if (status) tfb::dev_free(status);
         if (dir_var) tfb::dev_free(dir_var);
         if (dir_node) tfb::dev_free(dir_node);
-        tfb::stream_destroy(stream);
+        delete fallback;
+        if (owns_stream) tfb::stream_destroy(stream);
     }
 
     int64_t plane() const { return L1.plane; }
@@ -534,10 +536,10 @@ struct tf_solver {
         SlotMeta cur;
         cur.factor_c = factor_c; cur.cf_c = cf_c; cur.have_factor = have_factor; cur.cf_valid = cf_valid;
         cur.fact_checked = fact_checked; cur.fact_needs_refine = fact_needs_refine; cur.check_now = check_now;
-        cur.mon_this = mon_this; cur.cf_ver = cf_ver; cur.sweeps_needed = sweeps_needed;
+        cur.mon_this = mon_this; cur.cf_ver = cf_ver; cur.sweeps_needed = sweeps_needed; cur.delegated = delegated;
         factor_c = meta_alt.factor_c; cf_c = meta_alt.cf_c; have_factor = meta_alt.have_factor; cf_valid = meta_alt.cf_valid;
         fact_checked = meta_alt.fact_checked; fact_needs_refine = meta_alt.fact_needs_refine; check_now = meta_alt.check_now;
-        mon_this = meta_alt.mon_this; cf_ver = meta_alt.cf_ver; sweeps_needed = meta_alt.sweeps_needed;
+        mon_this = meta_alt.mon_this; cf_ver = meta_alt.cf_ver; sweeps_needed = meta_alt.sweeps_needed; delegated = meta_alt.delegated;
         meta_alt = cur;
         slot_id ^= 1;
     }
@@ -635,6 +637,16 @@ struct tf_solver {
     void factor(double c, const double* rhs1 = nullptr, double* x1 = nullptr) {
         if (!have_jac) throw std::runtime_error("tf_factor: no Jacobian evaluated yet (call tf_eval with_j=1)");
         factor_c = c;
+        delegated = false;
+        if (const Checked* like0 = checked_like(c); like0 && like0->replan && can_replan()) {
+            // this plan is known to break down for such a c: straight to the longer chunks
+            ++n_factor;
+            have_factor = true; cf_valid = jconst; cf_c = c; cf_ver = par_ver;
+            check_now = false; mon_this = false; fact_checked = true; sweeps_needed = 0;
+            delegate_factor(c);
+            if (rhs1) delegate_solve(rhs1, x1);
+            return;
+        }
         const bool fused = rhs1 != nullptr;
         for (size_t l = 0; l < levels.size(); ++l) {
             TfLevelArgs a = level_args(l, rhs1, x1);
@@ -713,11 +725,11 @@ struct tf_solver {
         }
     }
     // The two last levels of a solve go in one launch (tfk_cr_tail) when both are cyclic-reduction
-    // levels of 3 <= b <= 7 and the first of them has at most 8 chunks per system
+    // levels of 3 <= b <= 6 and the first of them has at most 8 chunks per system
     bool cr_tail = true;           // (TRIFLOW_CR_TAIL=0: A/B runs)
     bool tail_ok() const {
         const size_t n = levels.size();
-        return cr_tail && n >= 3 && top.B >= 3 && top.B <= 7 && levels[n - 1]->cr && levels[n - 2]->cr &&
+        return cr_tail && n >= 3 && top.B >= 3 && top.B <= 6 && levels[n - 1]->cr && levels[n - 2]->cr &&
                levels[n - 1]->L.P == 1 && levels[n - 2]->L.P <= 8;      // TF_CR_TAIL_MAXB, TF_CR_TAIL_WAVES
     }
     void solve_once(const double* rhs1, double* x1) {
@@ -770,6 +782,7 @@ struct tf_solver {
     // not pivot across blocks) is polished, this solve and the following ones.
     void solve(const double* rhs1, double* x1) {
         if (!have_factor) throw std::runtime_error("tf_solve: matrix not factorised");
+        if (delegated) { delegate_solve(rhs1, x1); return; }
         solve_once(rhs1, x1);
         polish(rhs1, x1);
     }
@@ -780,6 +793,46 @@ struct tf_solver {
     // elimination broke down (no pivoting across blocks), better loud than wrong.
     int sweeps_needed = 0;
     bool unstable = false;
+
+    // ---- re-planning: a child solver of the same model on the same stream with 8 x longer level-1
+    // chunks (and so on, down to one chunk per system), made when a factorisation of this plan
+    // cannot be refined to 1e-6.  The matrix and the right-hand sides travel through the natural
+    // node order (tfk_perm out of this layout, into the child's); the guard path only.
+    tf_solver* fallback = nullptr;
+    bool owns_stream = true;
+    int m1_used = 0, mup_used = 0;
+    bool delegated = false;        // the factorisation in memory lives in `fallback`
+    bool replan_on = true;         // (TRIFLOW_REPLAN=0: tests of the refusal itself)
+    bool can_replan() const { return replan_on && refine == -1 && !levels.empty() && levels[0]->L.P > 1; }
+    tf_solver* ensure_fallback();
+    void transfer_to(tf_solver* dst, const double* src_planes, double* dst_planes, int ncomp) {
+        ensure_staging((size_t)ncomp * nsys * N);
+        perm(1 /*OUT_SOA*/, src_planes, staging.p, ncomp);
+        dst->perm(0 /*IN_SOA*/, staging.p, dst_planes, ncomp);
+    }
+    void delegate_factor(double c) {
+        tf_solver* fb = ensure_fallback();
+        fb->mode = mode;
+        copy(fb->parsca.p, parsca.p, parsca.n * sizeof(double));
+        copy(fb->dx.p, dx.p, (size_t)nsys * sizeof(double));
+        ++fb->par_ver;
+        if (spec.parvec_mask) transfer_to(fb, parvec.p, fb->parvec.p, spec.npar);
+        if (spec.nnz > 0) transfer_to(fb, Jv.p, fb->Jv.p, spec.nnz);
+        fb->have_jac = true;
+        fb->have_factor = false;
+        fb->factor(c);
+        delegated = true;
+        fact_needs_refine = true;                    // (reported as "refined": the plan in use is not the one asked for)
+    }
+    void delegate_solve(const double* rhs1, double* x1) {
+        tf_solver* fb = fallback;
+        fb->mode = mode;
+        transfer_to(fb, rhs1, fb->Wrhs.p, spec.nvar);
+        fb->solve(fb->Wrhs.p, fb->Wstage.p);
+        fb->transfer_to(this, fb->Wstage.p, x1, spec.nvar);
+        last_omega = fb->last_omega;
+        if (fb->unstable) { fb->unstable = false; unstable = true; }
+    }
     void polish(const double* rhs1, double* x1) {
         if (refine > 0) {
             for (int it = 0; it < refine; ++it) refine_sweep(rhs1, x1);
@@ -804,11 +857,26 @@ struct tf_solver {
                 if (berr_adaptive)
                     berr_cur = (sweeps_needed == 0 && last_omega <= 0.01 * refine_trigger)
                         ? std::min(2 * berr_cur, std::max(berr_max, berr_every)) : berr_every;
-                if (!(last_omega <= 1e-6)) unstable = true;
-                if (Checked* e = checked_like(factor_c)) { e->c = factor_c; e->sweeps = sweeps_needed; e->at = n_factor; }
+                // A factorisation that refinement cannot bring below 1e-6 broke down (no pivoting across
+                // separators).  SuperLU never refuses a non-singular system (schemes.py:149, 557), so
+                // before giving up the library solves this matrix on a plan with 8 x longer level-1
+                // chunks (fewer separators; one chunk of a scalar model is a pivoted band LU): replan
+                // (the rescue is tried well before the refusal: where refinement was needed and leaves
+                // more than 1e-12 -- healthy plans read 1e-16 ... 7e-13 without any -- the elimination is
+                // losing digits that cond(A) multiplies in the solution)
+                bool replan = false;
+                if (sweeps_needed > 0 && !(last_omega <= 1e-12) && can_replan()) replan = true;
+                else if (!(last_omega <= 1e-6)) unstable = true;
+                if (Checked* e = checked_like(factor_c)) { e->c = factor_c; e->sweeps = sweeps_needed; e->at = n_factor; e->replan = replan; }
                 else {
                     if (checked.size() >= 4) checked.erase(checked.begin());
-                    checked.push_back(Checked{factor_c, sweeps_needed, n_factor});
+                    checked.push_back(Checked{factor_c, sweeps_needed, n_factor, replan});
+                }
+                if (replan) {
+                    ++n_replans;
+                    tfb::memset0(status, sizeof(int), stream);      // (what the abandoned plan may have flagged)
+                    delegate_factor(factor_c);
+                    delegate_solve(rhs1, x1);
                 }
             } else {
                 for (int it = 0; it < sweeps_needed; ++it) refine_sweep(rhs1, x1);
@@ -842,6 +910,7 @@ struct tf_solver {
             tfb::memset0(status, sizeof(int), stream);
             throw std::runtime_error("banded solver: singular or non-finite pivot block");
         }
+        if (fallback) fallback->check_status();
         if (unstable) {
             unstable = false;
             throw std::runtime_error("banded solver: the block elimination lost accuracy (backward error " +
@@ -888,10 +957,12 @@ int tf_model_create(const tf_model_spec* spec, const void* code, size_t size, tf
 
 void tf_model_destroy(tf_model* model) { delete model; }
 
-int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
-                     const tf_solver_opts* opts, tf_solver** out) {
-    TF_API_BEGIN
-    require(model && out, "tf_solver_create: null argument");
+}  // extern "C"
+namespace {
+// shared: the stream of the solver this one serves as the longer-chunk plan of (tf_solver::fallback)
+tf_solver* make_solver(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
+                       const tf_solver_opts* opts, tfb::Stream* shared) {
+    require(model != nullptr, "tf_solver_create: null argument");
     const tf_model_spec& sp = model->spec;
     require(nsys >= 1, "tf_solver_create: nsys must be >= 1");
     require(N >= 2 * sp.mp + 1, "tf_solver_create: the grid must hold at least one stencil window (N >= 2*mp+1)");
@@ -907,7 +978,9 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
     if (opts && opts->berr_every > 0) { s->berr_every = s->berr_cur = opts->berr_every; s->berr_adaptive = false; }
     if (opts && opts->device >= 0) tfb::set_device(opts->device);
     mup = std::max(mup, 2);
-    s->stream = tfb::stream_create();
+    if (shared) { s->stream = shared; s->owns_stream = false; }
+    else s->stream = tfb::stream_create();
+    if (const char* v = getenv("TRIFLOW_REPLAN")) s->replan_on = atoi(v) != 0;
     s->graphs_on = tfb::graphs_supported() && (int64_t)N * nsys <= 50000;
     if (const char* v = getenv("TRIFLOW_GRAPHS")) s->graphs_on = tfb::graphs_supported() && atoi(v) != 0;
     if (const char* v = getenv("TRIFLOW_FUSE_STAGE")) s->fuse_stage = atoi(v) != 0;      // A/B runs
@@ -939,6 +1012,7 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
             m1 = total <= 30000 ? 4 : (total <= 200000 ? 8 : (total <= 600000 ? 16 : 32));
     }
     m1 = std::max(m1, 2 * sp.mp);
+    s->m1_used = m1; s->mup_used = mup;
     {
         // Reduced levels: cyclic reduction inside 16-node chunks wherever the back end has the
         // kernels for this block size (b <= 8).  Round 1 kept the chunk walks (tfk_bt_*) for levels
@@ -992,7 +1066,29 @@ int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
     for (size_t l = 0; l < s->levels.size(); ++l) s->levels[l]->alloc(l, nsys, s->l1_respike, tot);
     s->top.alloc_top(b2, nsys, tot);
     s->topAinv.alloc((size_t)b2 * b2 * nsys, tot);
-    *out = s.release();
+    return s.release();
+}
+}  // namespace
+
+tf_solver* tf_solver::ensure_fallback() {
+    if (fallback) return fallback;
+    tf_solver_opts o;
+    std::memset(&o, 0, sizeof(o));
+    o.m1 = (int32_t)std::min<int64_t>(N, std::max<int64_t>(64, 8 * (int64_t)m1_used));
+    o.m_upper = 0; o.nstate = 1; o.refine = -1; o.device = -1;
+    o.berr_every = 1;                                // every factorisation of the rescue plan is checked
+    fallback = make_solver(model, N, nsys, periodic, &o, stream);
+    fallback->refine_trigger = 1e-14;                // the rescue polishes whatever it can (the guard path: time is no object)
+    bytes += fallback->bytes;
+    return fallback;
+}
+
+extern "C" {
+int tf_solver_create(tf_model* model, int64_t N, int32_t nsys, int32_t periodic,
+                     const tf_solver_opts* opts, tf_solver** out) {
+    TF_API_BEGIN
+    require(model && out, "tf_solver_create: null argument");
+    *out = make_solver(model, N, nsys, periodic, opts, nullptr);
     TF_API_END
 }
 
