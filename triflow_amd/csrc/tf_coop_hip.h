@@ -844,7 +844,8 @@ __device__ __forceinline__ void tfk_cr_tail_coop(const TfTailArgs& t) {
     }
     TF_STAMP(la, 52);
 #pragma unroll
-    for (int q = 0; q < NEF; ++q) sEF[w][lane + 64 * q < MAXLEN * 2 * B2 ? lane + 64 * q : 0] = ef[q];
+    for (int q = 0; q < NEF; ++q)
+        if (lane + 64 * q < MAXLEN * 2 * B2) sEF[w][lane + 64 * q] = ef[q];
 #pragma unroll
     for (int q = 0; q < NTOP; ++q) {
         const int i = (int)threadIdx.x + 64 * NW * q;

@@ -841,7 +841,10 @@ TF_DEVICE int tf_twist_h(int mI, int enabled) {
 // same launch).
 // (YLDS is a flag, not a null test of the pointer: testing an LDS pointer against NULL trips
 // hipcc 7.2 on some models, "Illegal instruction detected: V_CMP_NE_U32 0, $src_shared_base")
-template <class Rows, int DIR, bool SPIKE, bool STORE_U, bool STORE_Y, bool KNOWN = false, bool YLDS = false>
+// ZSEP (with KNOWN): the separator behind the walk counts as zero (tfk_l1_solve_twist: the interior
+// solution for zero separators, whose ends are the tips the next level's right-hand side is made of).
+template <class Rows, int DIR, bool SPIKE, bool STORE_U, bool STORE_Y, bool KNOWN = false, bool YLDS = false,
+          bool ZSEP = false>
 TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg, double* ylds = nullptr) {
     constexpr int B = Rows::B, MP = Rows::MP, W = 2 * MP + 1;
     static_assert(!KNOWN || (!SPIKE && !STORE_U), "the re-elimination takes one right-hand side");
@@ -869,7 +872,12 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg, double* ylds = nullp
     // interior is the last one)
     double sa[KNOWN ? MP : 1][B];
     const int hdn = tf_twist_h<B, MP>(mI, a.twist);  // nodes of the down half (a.respike)
-    if (KNOWN) {
+    if (KNOWN && ZSEP) {
+#pragma unroll
+        for (int t = 0; t < MP; ++t)
+#pragma unroll
+            for (int r = 0; r < B; ++r) sa[KNOWN ? t : 0][r] = 0.0;
+    } else if (KNOWN) {
         const int e = pg / L.P, p = pg - e * L.P;
         const bool has_sep = DIR < 0 || L.periodic || p > 0;
         const int ps = DIR < 0 ? p : (p > 0 ? p - 1 : L.P - 1);
@@ -1498,10 +1506,15 @@ TF_DEVICE bool tf_dense_solve(double (&S)[n][n], double (&g)[n]) {
 // in both threads) and then stream their own half outwards like tfk_backsub_body.
 // ylds_dn / ylds_up (optional): y of the two walks comes from the workgroup's LDS (see
 // tfk_chunk_body) instead of a.yt.
-template <class Rows, bool YLDS = false>
+// TIPS: the separators count as zero and nothing of the solution is kept but its MP nodes at either
+// end of the chunk, written as the y tips (TfTips::y) that tfk_l1_asm_rhs folds into the next
+// level's right-hand side -- what the full-length walks of tfk_l1_solve leave behind, from half the
+// eliminations (tfk_l1_solve_twist).
+template <class Rows, bool YLDS = false, bool TIPS = false>
 TF_DEVICE void tfk_backsub_twist_body(const TfLevelArgs& a, int pg, int dir,
                                       const double* ylds_dn = nullptr, const double* ylds_up = nullptr) {
     constexpr int B = Rows::B, MP = Rows::MP, NB = MP * B;
+    typedef TfTips<B, MP> Tip;
     static_assert(!Rows::PIVOT, "the re-elimination form is for block sizes that do not exchange rows");
     const TfLayout& L = a.L;
     if (pg >= L.Ptot) return;
@@ -1532,7 +1545,29 @@ TF_DEVICE void tfk_backsub_twist_body(const TfLevelArgs& a, int pg, int dir,
 #pragma unroll
                 for (int k = 0; k < B; ++k) U[c][r][k] = tf_ldp(a.Ut, (c * B + r) * B + k, L.plane, off);
     };
-    if (hu == 0 || dir == 0) {
+    // the solution at node `nd` (natural index inside the chunk): kept, or only where it is a tip
+    auto emit = [&](int nd, const double (&x)[B]) {
+        if (TIPS) {
+            if (nd < MP) {
+#pragma unroll
+                for (int r = 0; r < B; ++r) a.tips_up[(int64_t)Tip::y(nd, r) * L.Ptot + pg] = x[r];
+            }
+            if (nd >= mI - MP) {
+#pragma unroll
+                for (int r = 0; r < B; ++r) a.tips_dn[(int64_t)Tip::y(nd - (mI - MP), r) * L.Ptot + pg] = x[r];
+            }
+        } else {
+            const int64_t s = tf_idx(L, pg, nd);
+#pragma unroll
+            for (int r = 0; r < B; ++r) a.x[(int64_t)r * L.plane + s] = x[r];
+        }
+    };
+    if (TIPS) {
+#pragma unroll
+        for (int t = 0; t < MP; ++t)
+#pragma unroll
+            for (int r = 0; r < B; ++r) xn[t][r] = 0.0;
+    } else if (hu == 0 || dir == 0) {
         // the chunk's own separator: solved by the next level
         int p2, i2;
         tf_locate(a.Lnext, p, p2, i2);
@@ -1634,17 +1669,19 @@ TF_DEVICE void tfk_backsub_twist_body(const TfLevelArgs& a, int pg, int dir,
         if (dir == 0) {
 #pragma unroll
             for (int k = 0; k < MP; ++k) {
-                const int64_t s = tf_idx(L, pg, h - MP + k);
+                double xk[B];
 #pragma unroll
-                for (int r = 0; r < B; ++r) { a.x[(int64_t)r * L.plane + s] = Tg[k * B + r]; xn[k][r] = Tg[k * B + r]; }
+                for (int r = 0; r < B; ++r) { xk[r] = Tg[k * B + r]; xn[k][r] = Tg[k * B + r]; }
+                emit(h - MP + k, xk);
             }
             // (ahead of node h-MP-1: h-MP (a_0), h-MP+1 (a_1), ...)
         } else {
 #pragma unroll
             for (int k = 0; k < MP; ++k) {
-                const int64_t s = tf_idx(L, pg, h + k);
+                double xk[B];
 #pragma unroll
-                for (int r = 0; r < B; ++r) { a.x[(int64_t)r * L.plane + s] = g2[k * B + r]; xn[MP - 1 - k][r] = g2[k * B + r]; }
+                for (int r = 0; r < B; ++r) { xk[r] = g2[k * B + r]; xn[MP - 1 - k][r] = g2[k * B + r]; }
+                emit(h + k, xk);
             }
             // (ahead of node h+MP, walking up: h+MP-1 (b_{MP-1}), ...)
         }
@@ -1655,7 +1692,6 @@ TF_DEVICE void tfk_backsub_twist_body(const TfLevelArgs& a, int pg, int dir,
             const int j = j0 - d;
             if (j < 0) break;
             const Node& cur = ring[d];
-            const int64_t s = tf_idx(L, pg, nat(j));
             double x[B];
 #pragma unroll
             for (int r = 0; r < B; ++r) x[r] = cur.y[r];
@@ -1666,7 +1702,8 @@ TF_DEVICE void tfk_backsub_twist_body(const TfLevelArgs& a, int pg, int dir,
 #pragma unroll
                 for (int r = 0; r < B; ++r) xn[c][r] = xn[c - 1][r];
 #pragma unroll
-            for (int r = 0; r < B; ++r) { xn[0][r] = x[r]; a.x[(int64_t)r * L.plane + s] = x[r]; }
+            for (int r = 0; r < B; ++r) xn[0][r] = x[r];
+            emit(nat(j), x);
             if (j - D >= 0) load(j - D, ring[d]);
         }
     }

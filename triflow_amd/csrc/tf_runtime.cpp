@@ -553,6 +553,7 @@ struct tf_solver {
     bool l1_respike = false;       // level-1 spike response not stored (tf_args.h, TF_RESPIKE_*)
     int l1_twist = -1;             // -1: by the number of chunks; 0 / 1: TRIFLOW_L1_TWIST (tests, A/B runs)
     bool l1_fuse_backsub = true;   // twisted form: tfk_l1_fwd2_backsub (TRIFLOW_L1_FUSE_BACKSUB=0: two launches)
+    bool l1_solve_twist = true;    // ... and tfk_l1_solve_twist for the later solves (TRIFLOW_L1_SOLVE_TWIST=0: tfk_l1_solve)
     void stage_rhs(const double* Uin, int nterms, const double* const* ks, const double* ac,
                    const double* gc, double dt, double* y, const double* monitor_rhs) {
         if (!fuse_stage || monitor_due(monitor_rhs, nterms, gc)) {
@@ -699,23 +700,28 @@ struct tf_solver {
     // skip: that many of the last levels have been back-substituted already (1: the last level
     // inside its forward / factor kernel -- a cyclic-reduction level that folds the top block
     // in; 2: the two last levels by tfk_cr_tail)
+    // The twisted level-1 kernels that keep a walk's y in LDS (tfk_l1_fwd2_backsub, tfk_l1_solve_twist):
+    // bytes of dynamic LDS per workgroup, 0 = not for this solver / plan.  Rows = the longer half of
+    // the longest chunk (tf_twist_h of tf_kernels.h: chunks too short to split, and wide blocks, stay
+    // one-sided); sets a.ylds_rows.
+    unsigned l1_twist_lds(TfLevelArgs& a) const {
+        if (!(l1_respike && a.twist && l1_fuse_backsub && tfb::is_device_build())) return 0;
+        auto half = [&](int mI) { return (spec.mp * spec.nvar <= 6 && mI >= 4 * spec.mp) ? (mI + 1) / 2 : mI; };
+        const int mI_max = a.L.M - spec.mp;
+        a.ylds_rows = std::max(half(mI_max), a.L.rem > 0 ? half(mI_max - 1) : 0);
+        const size_t lds = (size_t)2 * a.ylds_rows * spec.nvar * 64 * sizeof(double);
+        return lds <= 64u * 1024u ? (unsigned)lds : 0u;
+    }
     void backsub_chain(const double* rhs1, double* x1, int skip) {
         for (size_t l = levels.size() - (size_t)skip; l-- > 0;) {
             TfLevelArgs a = level_args(l, rhs1, x1);
             if (l == 0) {
                 // (twisted: grid.y = 2, the down and the up half of every chunk, tf_twist_h)
                 const unsigned gy = a.twist ? 2u : 1u;
-                if (l1_respike && a.twist && l1_fuse_backsub && tfb::is_device_build()) {
-                    // both in one launch, y in LDS: rows = the longer half of the longest chunk
-                    // (tf_twist_h of tf_kernels.h: chunks too short to split, and wide blocks, stay one-sided)
-                    auto half = [&](int mI) { return (spec.mp * spec.nvar <= 6 && mI >= 4 * spec.mp) ? (mI + 1) / 2 : mI; };
-                    const int mI_max = a.L.M - spec.mp;
-                    a.ylds_rows = std::max(half(mI_max), a.L.rem > 0 ? half(mI_max - 1) : 0);
-                    const size_t lds = (size_t)2 * a.ylds_rows * spec.nvar * 64 * sizeof(double);
-                    if (lds <= 64u * 1024u) {
-                        launch(TFK_L1_FWD2_BACKSUB, cdiv(a.L.Ptot, 64), 1, 128, &a, sizeof(a), (unsigned)lds);
-                        continue;
-                    }
+                if (const unsigned lds = l1_twist_lds(a)) {
+                    // both in one launch, y in LDS
+                    launch(TFK_L1_FWD2_BACKSUB, cdiv(a.L.Ptot, 64), 1, 128, &a, sizeof(a), lds);
+                    continue;
                 }
                 if (l1_respike) launch(TFK_L1_FWD2, cdiv(a.L.Ptot, 64), gy, 64, &a, sizeof(a));
                 launch(l1_respike ? TFK_L1_BACKSUB_U : TFK_L1_BACKSUB, cdiv(a.L.Ptot, 64), gy, 64, &a, sizeof(a));
@@ -745,7 +751,11 @@ struct tf_solver {
             }
             TfLevelArgs a = level_args(l, rhs1, x1);
             unsigned gx = cdiv(a.L.Ptot, 64);
-            if (l == 0) launch(TFK_L1_SOLVE, gx, 2, 64, &a, sizeof(a));
+            if (l == 0) {
+                const unsigned lds = l1_solve_twist ? l1_twist_lds(a) : 0u;
+                if (lds) launch(TFK_L1_SOLVE_TWIST, gx, 1, 128, &a, sizeof(a), lds);
+                else launch(TFK_L1_SOLVE, gx, 2, 64, &a, sizeof(a));
+            }
             else if (levels[l]->cr) { launch(TFK_CR_FWD, (unsigned)a.L.Ptot, 1, cr_block(), &a, sizeof(a)); continue; }
             else launch(TFK_BT_RHS, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 2, 64, &a, sizeof(a));
             if (l == 0) launch(TFK_L1_ASM_RHS, gx, 1, asm_block(), &a, sizeof(a));
@@ -987,6 +997,7 @@ tf_solver* make_solver(tf_model* model, int64_t N, int32_t nsys, int32_t periodi
     if (const char* v = getenv("TRIFLOW_CR_TAIL")) s->cr_tail = atoi(v) != 0;
     if (const char* v = getenv("TRIFLOW_L1_FUSE_BACKSUB")) s->l1_fuse_backsub = atoi(v) != 0;
     if (const char* v = getenv("TRIFLOW_TWO_FACTORS")) s->two_slots = atoi(v) != 0;
+    if (const char* v = getenv("TRIFLOW_L1_SOLVE_TWIST")) s->l1_solve_twist = atoi(v) != 0;
     s->l1_respike = TF_RESPIKE_MODEL(sp.mp, sp.nvar) && (int64_t)N * nsys >= TF_RESPIKE_MIN_NODES;
     if (const char* v = getenv("TRIFLOW_L1_TWIST")) s->l1_twist = atoi(v) != 0 ? 1 : 0;
     if (const char* v = getenv("TRIFLOW_L1_RESPIKE"))                                   // A/B runs, tests
