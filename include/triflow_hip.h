@@ -77,6 +77,11 @@ int tf_set_device(int32_t ordinal);
 /* code object = gfx950 .hsaco image built from the generated per-model source */
 int tf_model_create(const tf_model_spec* spec, const void* code_object, size_t code_size,
                     tf_model** out);
+/* Second build of the same code object (lower optimisation level): the kernels whose bit
+ * is set in kernel_mask (index = tf_kernel_name) are launched from it.  The compiler plugin
+ * uses it for kernels that spill registers to scratch at -O3 (wide models). */
+int tf_model_add_alternate(tf_model* model, const void* code_object, size_t code_size,
+                           uint64_t kernel_mask);
 void tf_model_destroy(tf_model* model);
 
 /* nsys independent systems (ensemble members) of N nodes each share one solver */

@@ -39,6 +39,7 @@ void h2d(void* d, const void* s, size_t n, Stream*) { std::memcpy(d, s, n); }
 void d2h(void* d, const void* s, size_t n, Stream*) { std::memcpy(d, s, n); }
 void d2d(void* d, const void* s, size_t n, Stream*) { std::memmove(d, s, n); }
 Module* module_load(const void*, size_t) { return new Module(); }
+void module_add_alternate(Module*, const void*, size_t, uint64_t) {}
 void module_unload(Module* m) { delete m; }
 Stream* stream_create() { return new Stream(); }
 void stream_destroy(Stream* s) { delete s; }

@@ -82,6 +82,35 @@ def check_FJ_bitexact_large(name, backend, N):
 
 
 # ---------------------------------------------------------------- seam #3: solver
+def check_proportional_entries(backend):
+    """Jacobian entries that the generated code marks as a power-of-two multiple of another entry
+    (codegen._proportional_entries: the solver walks, J @ v and the monitors load one and scale)
+    are that multiple *bit for bit* in the value table the sweep writes -- per-node parameters
+    included -- and the models of BASELINE have some (film: 3, stiff: 3)."""
+    found = {}
+    for name in ("M3_film", "M5_stiff", "wide4", "burgers", "M1_advdiff"):
+        m = device_model(name, backend)
+        for per_node in (False, True):
+            fd = corpus.synthetic_fields(name, 301, seed=9, periodic=True)
+            pars = corpus.synthetic_pars(name, 301, True, per_node)
+            cm = m._device
+            solver = cm.solver(301, True, 1, cm.parvec_mask_of([pars[k] for k in cm.pars]))
+            cm.bind_inputs(solver, fd["x"], [pars[k] for k in cm.pars],
+                           [fd[k] for k in m._help_funcs] if cm.nh else None)
+            solver.set_state(0, np.array([fd[k] for k in m._dep_vars]))
+            solver.eval(0, with_j=True)
+            table = solver.get_J()[0]                              # [N][nnz]
+            spec = solver.model.spec
+            pairs = [(k, a, sc) for k, (a, sc) in enumerate(zip(spec["j_alias"], spec["j_alias_scale"])) if a >= 0]
+            if not per_node:
+                found[name] = len(pairs)
+            for k, a, sc in pairs:
+                assert not spec["j_uniform"][k] and not spec["j_uniform"][a] and spec["j_alias"][a] < 0
+                assert abs(sc) == 2.0 ** round(np.log2(abs(sc)))
+                assert np.array_equal(table[:, k], sc * table[:, a]), (name, per_node, k, a, sc)
+    assert found["M3_film"] == 3 and found["M5_stiff"] == 3 and found["burgers"] == 0, found
+
+
 def bound_solver(m, fd, pars, **opts):
     cm = m._device
     N = fd["x"].size

@@ -40,6 +40,7 @@ SIGNATURES = {
     "tf_set_device": (C.c_int, [C.c_int32]),
     "tf_model_create": (C.c_int, [C.POINTER(ModelSpec), C.c_void_p, C.c_size_t,
                                   C.POINTER(C.c_void_p)]),
+    "tf_model_add_alternate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64]),
     "tf_model_destroy": (None, [C.c_void_p]),
     "tf_solver_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                    C.POINTER(SolverOpts), C.POINTER(C.c_void_p)]),
@@ -141,7 +142,7 @@ class Library:
 class DeviceModel:
     """``tf_model``: a loaded per-model code object."""
 
-    def __init__(self, lib, spec, code):
+    def __init__(self, lib, spec, code, alt_code=None, alt_kernels=()):
         self.lib = lib
         self.spec = dict(spec)
         cs = ModelSpec(spec["nvar"], spec["nh"], spec["npar"], spec["mp"], spec["nnz"],
@@ -152,6 +153,14 @@ class DeviceModel:
                  C.cast(self._code, C.c_void_p) if self._code is not None else None,
                  len(code) if code else 0, C.byref(handle))
         self.handle = handle
+        self._alt = None
+        if alt_code and alt_kernels:
+            names = lib.kernel_names()
+            mask = 0
+            for k in alt_kernels:
+                mask |= 1 << names.index(k)
+            self._alt = C.create_string_buffer(alt_code, len(alt_code))
+            lib.call("tf_model_add_alternate", handle, C.cast(self._alt, C.c_void_p), len(alt_code), mask)
 
     def close(self):
         if self.handle:

@@ -262,6 +262,8 @@ def lower_model(model, parvec_mask=0, seg=8, sweep_block=64):
     # thread instead of reading them back from the value table at every node
     j_uniform = [1 if emit_j.is_uniform(n) else 0 for n in j_nodes]
 
+    j_alias, j_alias_scale = _proportional_entries(model, j_uniform)
+
     def body(outname, exprs, emitter, only=None):
         lines = ["    " + d for d in decls if only is None or d.split("=")[1].strip().startswith("par[")]
         lines += ["    const double* tf_hc = par + %d;" % len(pars)]
@@ -297,6 +299,7 @@ def lower_model(model, parvec_mask=0, seg=8, sweep_block=64):
         arr("tf_pat_eq", pat_eq), arr("tf_pat_var", pat_var), arr("tf_pat_off", pat_off),
         arr("tf_par_is_vec", par_is_vec, "bool"),
         arr("tf_j_uniform", j_uniform, "bool"),
+        arr("tf_j_alias", j_alias), arr("tf_j_alias_scale", [_dbl(v) for v in j_alias_scale], "double"),
         "TF_DEVICE void tf_eval_F(const double (&w)[TF_NVAR + TF_NH][2 * TF_MP + 1], "
         "const double* par, double dx, double xc, double* F) {",
         body("F", f_c, emit_f),
@@ -315,8 +318,65 @@ def lower_model(model, parvec_mask=0, seg=8, sweep_block=64):
                 host_consts=hc_list, mp=mp, nnz=nnz, seg=seg,
                 sweep_block=sweep_block, uses_x=int(uses_x), parvec_mask=int(parvec_mask),
                 b2=mp * nvar, pat_eq=pat_eq, pat_var=pat_var, pat_off=pat_off, j_uniform=j_uniform,
+                j_alias=j_alias, j_alias_scale=j_alias_scale,
                 fields=fields, pars=pars)
     return src, spec
+
+
+def _proportional_entries(model, j_uniform):
+    """Jacobian entries that are an exact power-of-two multiple of an earlier node-dependent
+    entry (``-q*dxT/h`` differentiated with respect to ``T_m1`` and ``T_p1``; ``We*h*dxxxh`` with
+    respect to the four neighbours of ``h``; a reaction term that enters two equations with
+    opposite signs): the kernels that read the value table back load one of them and scale.
+    ``alias[k]`` = index of the entry to load (-1: none), ``scale[k]`` = +-2**n.  Accepted only if
+    (i) SymPy proves the proportionality and (ii) the two expressions, evaluated the way the
+    reference evaluates them (the lambdified NumPy code whose operation tree the C code repeats),
+    agree *bit for bit* on random inputs -- scaling by a power of two commutes with every
+    rounding, a different association of the same product would not."""
+    exprs = model._J_sparse_array.tolist()
+    nnz = len(exprs)
+    alias, scale = [-1] * nnz, [1.0] * nnz
+    cand = [k for k in range(nnz) if not j_uniform[k]]
+    if len(cand) < 2:
+        return alias, scale
+    func = lambdify(model._symbolic_args, exprs, modules=[{"Heaviside": lambda *a: 1}, "numpy"], cse=False)
+    rng = np.random.default_rng(12345)
+    samples = []
+    for _ in range(2):
+        args = [rng.uniform(0.5, 2.0, 257) * rng.choice([-1.0, 1.0], 257) for _ in model._symbolic_args]
+        with np.errstate(all="ignore"):
+            vals = func(*args)
+        samples.append([np.broadcast_to(np.asarray(v, dtype=float), (257,)) for v in vals])
+    for k in cand:
+        for m in cand:
+            if m >= k:
+                break
+            if alias[m] >= 0:
+                continue
+            a0, b0 = samples[0][k], samples[0][m]
+            if not (np.isfinite(a0).all() and np.isfinite(b0).all()) or not np.all(b0 != 0.0):
+                continue
+            r = a0[0] / b0[0]
+            mant, _ = np.frexp(abs(r))
+            if not (np.isfinite(r) and r != 0.0 and mant == 0.5):
+                continue
+            if not all(np.array_equal(smp[k], r * smp[m]) for smp in samples):
+                continue
+            if sympy_simplify(exprs[k] - sympy_Float_exact(r) * exprs[m]) != 0:
+                continue
+            alias[k], scale[k] = m, float(r)
+            break
+    return alias, scale
+
+
+def sympy_Float_exact(r):
+    import sympy
+    return sympy.Rational(*float(r).as_integer_ratio())
+
+
+def sympy_simplify(e):
+    import sympy
+    return sympy.simplify(e)
 
 
 _HOST_NS = {name: getattr(np, name) for name in

@@ -27,6 +27,7 @@ import re
 import shutil
 import subprocess
 import threading
+import warnings
 
 import numpy as np
 import scipy.sparse as sps
@@ -129,9 +130,9 @@ def _compile_code_object(model, source, tag, hsaco):
     tmp = hsaco + ".%d.tmp" % os.getpid()
     log.info("hipcc: compiling stencil + solver kernels for %s", model._diff_eqs)
 
-    def compile_with(flags):
+    def compile_with(flags, out):
         cmd = [_hipcc(), *flags, "-I", CSRC, "--genco", "--no-gpu-bundle-output",
-               "-Rpass-analysis=kernel-resource-usage", "-o", tmp, hip]
+               "-Rpass-analysis=kernel-resource-usage", "-o", out, hip]
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError("hipcc failed on the generated kernels (%s):\n%s"
@@ -139,25 +140,50 @@ def _compile_code_object(model, source, tag, hsaco):
         return _parse_resource_usage(res.stderr)
 
     flags = list(HIPCC_FLAGS)
-    usage = compile_with(flags)
-    spilled = [k for k, u in usage.items() if u.get("ScratchSize", 0) > 0]
+    usage = compile_with(flags, tmp)
+    spilled = sorted(k for k, u in usage.items() if u.get("ScratchSize", 0) > 0)
+    alt_flags, alt_usage = None, None
+    alt = hsaco[:-len(".hsaco")] + ".alt.hsaco"
     if spilled and "-O1" not in flags and "-O0" not in flags \
             and os.environ.get("TRIFLOW_ALLOW_SCRATCH") != "1":          # (A/B runs)
         # Round 1 saw wrong solves from solver kernels that spill to scratch at -O2/-O3 (wide
         # blocks: error 0.3 at -O3, 6e-15 at -O1); round 2 could not reproduce it (DESIGN.md
-        # "compiler notes"), the conservative gate stays: such a model is built at -O1 --
-        # slower, but it spills anyway
-        log.warning("kernels with scratch spills for %s at %s: %s; rebuilding at -O1",
-                    model._diff_eqs, flags[0], spilled)
-        flags = ["-O1"] + [f for f in flags if not f.startswith("-O")]
-        usage = compile_with(flags)
+        # "compiler notes"), the conservative gate stays -- per kernel since round 3: the kernels
+        # that spill are taken from a second build of the same source at -O1 (they spill there
+        # too, correctly), every other kernel keeps its -O3 build.  TRIFLOW_SPILL_GATE=object
+        # restores the round-2 behaviour (the whole code object at -O1).
+        warnings.warn("triflow_amd: %d kernel(s) of the model %s need more registers than a wavefront has "
+                      "(%s spill to scratch): those kernels are built at -O1 and run slower than the "
+                      "narrow-model path (DESIGN.md, solver limits)"
+                      % (len(spilled), list(model._diff_eqs), ", ".join(spilled)), RuntimeWarning, stacklevel=3)
+        alt_flags = ["-O1"] + [f for f in flags if not f.startswith("-O")]
+        if os.environ.get("TRIFLOW_SPILL_GATE") == "object":
+            flags, alt_flags = alt_flags, None
+            usage = compile_with(flags, tmp)
+        else:
+            alt_usage = compile_with(alt_flags, alt + ".%d.tmp" % os.getpid())
+            os.replace(alt + ".%d.tmp" % os.getpid(), alt)
     meta = os.path.join(CACHE_DIR, "model_%s.json" % tag)
     with open(meta + ".%d.tmp" % os.getpid(), "w") as f:
         json.dump(dict(equations=list(model._diff_eqs), flags=flags, kernels=usage,
+                       alt_flags=alt_flags, alt_kernels=spilled if alt_flags else [],
+                       alt_usage={k: alt_usage[k] for k in spilled} if alt_usage else {},
                        skeleton=_skeleton_stamp(), hipcc=hipcc_version()), f, indent=1)
     os.replace(meta + ".%d.tmp" % os.getpid(), meta)
     os.replace(tmp, hsaco)
     evict_stale_cache()
+
+
+def alternate_of(hsaco_path):
+    """(path of the second build, kernels taken from it) of a cached code object, or (None, [])."""
+    try:
+        with open(hsaco_path[:-len(".hsaco")] + ".json") as f:
+            meta = json.load(f)
+    except (OSError, ValueError):
+        return None, []
+    alt = hsaco_path[:-len(".hsaco")] + ".alt.hsaco"
+    kernels = meta.get("alt_kernels") or []
+    return (alt, kernels) if kernels and os.path.exists(alt) else (None, [])
 
 
 def build_code_object(model, parvec_mask=0, seg=None, sweep_block=None):
@@ -170,7 +196,7 @@ def build_code_object(model, parvec_mask=0, seg=None, sweep_block=None):
     waves = int(os.environ.get("TRIFLOW_SWEEP_WAVES", "0"))
     knobs = (_NT_STORE if nt else "") + ("#define TF_SWEEP_WAVES %d\n" % waves if waves else "")
     source = _TU_HEAD % knobs + body + _TU_TAIL
-    tag = codegen.source_hash(source, _skeleton_stamp(), " ".join(HIPCC_FLAGS), hipcc_version(), "elf")
+    tag = codegen.source_hash(source, _skeleton_stamp(), " ".join(HIPCC_FLAGS), hipcc_version(), os.environ.get("TRIFLOW_SPILL_GATE", "kernel"), "elf")
     os.makedirs(CACHE_DIR, exist_ok=True)
     hsaco = os.path.join(CACHE_DIR, "model_%s.hsaco" % tag)
     if not os.path.exists(hsaco):
@@ -238,7 +264,7 @@ def evict_stale_cache(keep=()):
             continue
         if os.path.basename(base) in keep:
             continue
-        for ext in (".hsaco", ".hip", ".json"):
+        for ext in (".hsaco", ".alt.hsaco", ".hip", ".json"):
             try:
                 os.remove(base + ext)
                 removed += 1
@@ -270,7 +296,12 @@ class HipBackend:
             lib.set_device(device)          # the code object belongs to this GPU
         with open(hsaco, "rb") as f:
             code = f.read()
-        return DeviceModel(lib, spec, code)
+        alt, alt_kernels = alternate_of(hsaco)
+        alt_code = None
+        if alt:
+            with open(alt, "rb") as f:
+                alt_code = f.read()
+        return DeviceModel(lib, spec, code, alt_code, alt_kernels)
 
 
 _default_backend = HipBackend()

@@ -31,6 +31,9 @@ void d2h(void* dst, const void* src, size_t bytes, Stream* s);     // synchronou
 void d2d(void* dst, const void* src, size_t bytes, Stream* s);
 
 Module* module_load(const void* image, size_t bytes);
+// kernels whose bit is set in `mask` (kernel table index) are taken from a second build of the
+// same translation unit (the per-kernel optimisation gate of compilers.py)
+void module_add_alternate(Module* m, const void* image, size_t bytes, uint64_t mask);
 void module_unload(Module* m);
 
 Stream* stream_create();

@@ -22,7 +22,7 @@ static void check(hipError_t err, const char* what) {
 }
 #define TF_HIP(call) check((call), #call)
 
-struct Module { hipModule_t mod; hipFunction_t fn[TFK_COUNT]; };
+struct Module { hipModule_t mod; hipFunction_t fn[TFK_COUNT]; hipModule_t alt = nullptr; };
 struct Stream { hipStream_t s; };
 struct Event { hipEvent_t e; };
 
@@ -199,8 +199,20 @@ Module* module_load(const void* image, size_t) {
     }
     return m;
 }
+void module_add_alternate(Module* m, const void* image, size_t, uint64_t mask) {
+    static const char* names[TFK_COUNT] = TF_KERNEL_NAMES;
+    if (!m || !mask) return;
+    if (m->alt) throw std::runtime_error("module_add_alternate: one alternate build per model");
+    check(hipModuleLoadData(&m->alt, image), "hipModuleLoadData (alternate build)");
+    for (int k = 0; k < TFK_COUNT; ++k)
+        if ((mask >> k) & 1ull) {
+            if (hipModuleGetFunction(&m->fn[k], m->alt, names[k]) != hipSuccess)
+                throw std::runtime_error(std::string("kernel missing from the alternate code object: ") + names[k]);
+        }
+}
 void module_unload(Module* m) {
     if (!m) return;
+    if (m->alt) (void)hipModuleUnload(m->alt);
     (void)hipModuleUnload(m->mod);
     delete m;
 }

@@ -184,23 +184,6 @@ __global__ void __launch_bounds__(128) tfk_l1_fwd2_backsub(TfLevelArgs a) {
         tfk_backsub_twist_body<TfRowsL1, true>(a, pg, dir, ydn, yup);
     }
 }
-// The forward part of a later solve (tfk_l1_solve: both walks over the whole chunk, for the y tips
-// alone) in the same twisted form: each wavefront eliminates its half with the separators taken as
-// zero, the middle system is solved, and the back-substitution with the stored U runs out to the
-// ends of the chunk, whose MP nodes are the tips.  Half the eliminations -- the expensive part: they
-// are recomputed from J -- for a back-substitution of the other half; nothing but the tips is written.
-__global__ void __launch_bounds__(128) tfk_l1_solve_twist(TfLevelArgs a) {
-    if constexpr (TF_RESPIKE_MODEL(TF_MP, TF_NVAR)) {
-        extern __shared__ double tf_dyn_lds[];
-        const int lane = threadIdx.x & 63, dir = threadIdx.x >> 6, pg = blockIdx.x * 64 + lane;
-        double* ydn = tf_dyn_lds + lane;
-        double* yup = tf_dyn_lds + (size_t)a.ylds_rows * TF_NVAR * 64 + lane;
-        if (dir == 0) tfk_chunk_body<TfRowsL1, +1, false, false, true, true, true, true>(a, pg, ydn);
-        else tfk_chunk_body<TfRowsL1, -1, false, false, true, true, true, true>(a, pg, yup);
-        __syncthreads();
-        tfk_backsub_twist_body<TfRowsL1, true, true>(a, pg, dir, ydn, yup);
-    }
-}
 // The next level's rows.  When that level keeps records per node (cyclic reduction), the 64
 // rows of a workgroup are collected in LDS and leave as whole records: coalesced stores of
 // 3*b*b contiguous doubles per separator instead of 8 bytes per lane and instruction.

@@ -118,6 +118,13 @@ TF_DEVICE int64_t tf_next_x(const TfLevelArgs& a, int e, int p, int64_t s2, int 
 #define TF_USE_JUNIFORM 1          // 0: read every entry back (A/B runs)
 #endif
 #define TF_JU(k) (TF_USE_JUNIFORM && tf_j_uniform[k])
+// ... and entries that are an exact power-of-two multiple of another node-dependent entry
+// (tf_j_alias / tf_j_alias_scale, codegen._proportional_entries: same bits as the stored value):
+// one load serves both.  Film model: 7 planes are loaded instead of 10.
+#ifndef TF_USE_JALIAS
+#define TF_USE_JALIAS 1            // 0: load every node-dependent entry (A/B runs)
+#endif
+#define TF_JA(k) (TF_USE_JALIAS && !TF_JU(k) && tf_j_alias[k] >= 0)
 struct TfJUniform {
     double v[TF_NNZ > 0 ? TF_NNZ : 1];
     TF_DEVICE_M void init(const double* parsca, const double* dxp, int nsys, int e) {
@@ -125,6 +132,14 @@ struct TfJUniform {
 #pragma unroll
         for (int k = 0; k < TF_NPAR; ++k) par[k] = tf_par_is_vec[k] ? 0.0 : parsca[k * nsys + e];
         tf_eval_J_uniform(par, dxp[e], v);
+    }
+    // the value table row of a node: ld(k) loads entry k; evaluated / scaled entries are not loaded
+    template <class Ld>
+    TF_DEVICE_M void row(Ld ld, double (&jr)[TF_NNZ > 0 ? TF_NNZ : 1]) const {
+#pragma unroll
+        for (int k = 0; k < TF_NNZ; ++k)
+            jr[k] = TF_JU(k) ? v[k]
+                  : (TF_JA(k) ? tf_j_alias_scale[k] * jr[tf_j_alias[k] >= 0 ? tf_j_alias[k] : 0] : ld(k));
     }
 };
 
@@ -210,9 +225,11 @@ TF_DEVICE void tfk_sweep_body(const TfSweepArgs& a, int pg, int seg) {
                 double acc[TF_NVAR];
 #pragma unroll
                 for (int v = 0; v < TF_NVAR; ++v) acc[v] = 0.0;
+                double jr[TF_NNZ > 0 ? TF_NNZ : 1];
+                ju.row([&](int k) { return tf_ldp(a.Jv, k, L.plane, off); }, jr);
 #pragma unroll
                 for (int k = 0; k < TF_NNZ; ++k) {       // tfk_spmv_body, scale = 1
-                    const double jv = 1.0 * (TF_JU(k) ? ju.v[k] : tf_ldp(a.Jv, k, L.plane, off));
+                    const double jv = 1.0 * jr[k];
                     acc[tf_pat_eq[k]] = acc[tf_pat_eq[k]] +
                         jv * wv[STAGE_RHS ? tf_pat_var[k] : 0][tf_pat_off[k] + TF_MP];
                 }
@@ -306,9 +323,11 @@ TF_DEVICE double tfk_spmv_body(const TfSpmvArgs& a, int pg, int seg) {
 #pragma unroll
             for (int v = 0; v < TF_NVAR; ++v) { acc[v] = 0.0; mag[v] = 0.0; }
             constexpr bool mon = MON;
+            double jr[TF_NNZ > 0 ? TF_NNZ : 1];
+            ju.row([&](int k) { return tf_ldp(a.Jv, k, L.plane, (unsigned)s * 8u); }, jr);
 #pragma unroll
             for (int k = 0; k < TF_NNZ; ++k) {       // pattern order = ascending column
-                double jv = a.scale * (TF_JU(k) ? ju.v[k] : tf_ldp(a.Jv, k, L.plane, (unsigned)s * 8u));
+                double jv = a.scale * jr[k];
                 double wv = w[tf_pat_var[k]][tf_pat_off[k] + TF_MP];
                 if (a.absval) { jv = tf_abs(jv); wv = tf_abs(wv); }
                 acc[tf_pat_eq[k]] = acc[tf_pat_eq[k]] + jv * wv;
@@ -375,9 +394,11 @@ TF_DEVICE double tfk_berr_body(const TfBerrArgs& a, int pg, int seg) {
             double acc[TF_NVAR], mag[TF_NVAR];
 #pragma unroll
             for (int v = 0; v < TF_NVAR; ++v) { acc[v] = 0.0; mag[v] = 0.0; }
+            double jr[TF_NNZ > 0 ? TF_NNZ : 1];
+            ju.row([&](int k) { return a.Jv[(int64_t)k * L.plane + s]; }, jr);
 #pragma unroll
             for (int k = 0; k < TF_NNZ; ++k) {
-                const double jv = a.c * (TF_JU(k) ? ju.v[k] : a.Jv[(int64_t)k * L.plane + s]);
+                const double jv = a.c * jr[k];
                 const double wv = w[tf_pat_var[k]][tf_pat_off[k] + TF_MP];
                 acc[tf_pat_eq[k]] = acc[tf_pat_eq[k]] + jv * wv;
                 mag[tf_pat_eq[k]] = mag[tf_pat_eq[k]] + tf_abs(jv) * tf_abs(wv);
@@ -701,8 +722,7 @@ struct TfRowsL1 {
     TF_DEVICE_M void request(int i, Raw& r) const {
         // (plane base in scalar registers + a 32-bit lane offset: planes are < 4 GB, tf_solver_create)
         const unsigned off = tf_off8(a.L, pg, i);
-#pragma unroll
-        for (int k = 0; k < TF_NNZ; ++k) r.jv[k] = TF_JU(k) ? ju.v[k] : tf_ldp(a.Jv, k, a.L.plane, off);
+        ju.row([&](int k) { return tf_ldp(a.Jv, k, a.L.plane, off); }, r.jv);
     }
     TF_DEVICE_M void decode(int i, const Raw& raw, double (&row)[2 * TF_MP + 1][TF_NVAR][TF_NVAR]) const {
 #pragma unroll
@@ -841,10 +861,7 @@ TF_DEVICE int tf_twist_h(int mI, int enabled) {
 // same launch).
 // (YLDS is a flag, not a null test of the pointer: testing an LDS pointer against NULL trips
 // hipcc 7.2 on some models, "Illegal instruction detected: V_CMP_NE_U32 0, $src_shared_base")
-// ZSEP (with KNOWN): the separator behind the walk counts as zero (tfk_l1_solve_twist: the interior
-// solution for zero separators, whose ends are the tips the next level's right-hand side is made of).
-template <class Rows, int DIR, bool SPIKE, bool STORE_U, bool STORE_Y, bool KNOWN = false, bool YLDS = false,
-          bool ZSEP = false>
+template <class Rows, int DIR, bool SPIKE, bool STORE_U, bool STORE_Y, bool KNOWN = false, bool YLDS = false>
 TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg, double* ylds = nullptr) {
     constexpr int B = Rows::B, MP = Rows::MP, W = 2 * MP + 1;
     static_assert(!KNOWN || (!SPIKE && !STORE_U), "the re-elimination takes one right-hand side");
@@ -872,12 +889,7 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg, double* ylds = nullp
     // interior is the last one)
     double sa[KNOWN ? MP : 1][B];
     const int hdn = tf_twist_h<B, MP>(mI, a.twist);  // nodes of the down half (a.respike)
-    if (KNOWN && ZSEP) {
-#pragma unroll
-        for (int t = 0; t < MP; ++t)
-#pragma unroll
-            for (int r = 0; r < B; ++r) sa[KNOWN ? t : 0][r] = 0.0;
-    } else if (KNOWN) {
+    if (KNOWN) {
         const int e = pg / L.P, p = pg - e * L.P;
         const bool has_sep = DIR < 0 || L.periodic || p > 0;
         const int ps = DIR < 0 ? p : (p > 0 ? p - 1 : L.P - 1);
@@ -1506,15 +1518,10 @@ TF_DEVICE bool tf_dense_solve(double (&S)[n][n], double (&g)[n]) {
 // in both threads) and then stream their own half outwards like tfk_backsub_body.
 // ylds_dn / ylds_up (optional): y of the two walks comes from the workgroup's LDS (see
 // tfk_chunk_body) instead of a.yt.
-// TIPS: the separators count as zero and nothing of the solution is kept but its MP nodes at either
-// end of the chunk, written as the y tips (TfTips::y) that tfk_l1_asm_rhs folds into the next
-// level's right-hand side -- what the full-length walks of tfk_l1_solve leave behind, from half the
-// eliminations (tfk_l1_solve_twist).
-template <class Rows, bool YLDS = false, bool TIPS = false>
+template <class Rows, bool YLDS = false>
 TF_DEVICE void tfk_backsub_twist_body(const TfLevelArgs& a, int pg, int dir,
                                       const double* ylds_dn = nullptr, const double* ylds_up = nullptr) {
     constexpr int B = Rows::B, MP = Rows::MP, NB = MP * B;
-    typedef TfTips<B, MP> Tip;
     static_assert(!Rows::PIVOT, "the re-elimination form is for block sizes that do not exchange rows");
     const TfLayout& L = a.L;
     if (pg >= L.Ptot) return;
@@ -1545,29 +1552,12 @@ TF_DEVICE void tfk_backsub_twist_body(const TfLevelArgs& a, int pg, int dir,
 #pragma unroll
                 for (int k = 0; k < B; ++k) U[c][r][k] = tf_ldp(a.Ut, (c * B + r) * B + k, L.plane, off);
     };
-    // the solution at node `nd` (natural index inside the chunk): kept, or only where it is a tip
-    auto emit = [&](int nd, const double (&x)[B]) {
-        if (TIPS) {
-            if (nd < MP) {
+    auto emit = [&](int nd, const double (&x)[B]) {     // the solution at node `nd` of the chunk
+        const int64_t s = tf_idx(L, pg, nd);
 #pragma unroll
-                for (int r = 0; r < B; ++r) a.tips_up[(int64_t)Tip::y(nd, r) * L.Ptot + pg] = x[r];
-            }
-            if (nd >= mI - MP) {
-#pragma unroll
-                for (int r = 0; r < B; ++r) a.tips_dn[(int64_t)Tip::y(nd - (mI - MP), r) * L.Ptot + pg] = x[r];
-            }
-        } else {
-            const int64_t s = tf_idx(L, pg, nd);
-#pragma unroll
-            for (int r = 0; r < B; ++r) a.x[(int64_t)r * L.plane + s] = x[r];
-        }
+        for (int r = 0; r < B; ++r) a.x[(int64_t)r * L.plane + s] = x[r];
     };
-    if (TIPS) {
-#pragma unroll
-        for (int t = 0; t < MP; ++t)
-#pragma unroll
-            for (int r = 0; r < B; ++r) xn[t][r] = 0.0;
-    } else if (hu == 0 || dir == 0) {
+    if (hu == 0 || dir == 0) {
         // the chunk's own separator: solved by the next level
         int p2, i2;
         tf_locate(a.Lnext, p, p2, i2);

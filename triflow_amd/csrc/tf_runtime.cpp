@@ -553,7 +553,6 @@ struct tf_solver {
     bool l1_respike = false;       // level-1 spike response not stored (tf_args.h, TF_RESPIKE_*)
     int l1_twist = -1;             // -1: by the number of chunks; 0 / 1: TRIFLOW_L1_TWIST (tests, A/B runs)
     bool l1_fuse_backsub = true;   // twisted form: tfk_l1_fwd2_backsub (TRIFLOW_L1_FUSE_BACKSUB=0: two launches)
-    bool l1_solve_twist = true;    // ... and tfk_l1_solve_twist for the later solves (TRIFLOW_L1_SOLVE_TWIST=0: tfk_l1_solve)
     void stage_rhs(const double* Uin, int nterms, const double* const* ks, const double* ac,
                    const double* gc, double dt, double* y, const double* monitor_rhs) {
         if (!fuse_stage || monitor_due(monitor_rhs, nterms, gc)) {
@@ -604,6 +603,18 @@ struct tf_solver {
     // level-1 assemble kernels: a wavefront per separator node on the GPU (tf_entry_hip.h)
     unsigned asm_block() const { return tfb::is_device_build() ? 64u * (unsigned)spec.mp : 64u; }
     Level& next_of(size_t l) { return l + 1 < levels.size() ? *levels[l + 1] : top; }
+    // The twisted level-1 kernels that keep a walk's y in LDS (tfk_l1_fwd2_backsub):
+    // bytes of dynamic LDS per workgroup, 0 = not for this solver / plan.  Rows = the longer half of
+    // the longest chunk (tf_twist_h of tf_kernels.h: chunks too short to split, and wide blocks, stay
+    // one-sided); sets a.ylds_rows.
+    unsigned l1_twist_lds(TfLevelArgs& a) const {
+        if (!(l1_respike && a.twist && l1_fuse_backsub && tfb::is_device_build())) return 0;
+        auto half = [&](int mI) { return (spec.mp * spec.nvar <= 6 && mI >= 4 * spec.mp) ? (mI + 1) / 2 : mI; };
+        const int mI_max = a.L.M - spec.mp;
+        a.ylds_rows = std::max(half(mI_max), a.L.rem > 0 ? half(mI_max - 1) : 0);
+        const size_t lds = (size_t)2 * a.ylds_rows * spec.nvar * 64 * sizeof(double);
+        return lds <= 64u * 1024u ? (unsigned)lds : 0u;
+    }
     TfLevelArgs level_args(size_t l, const double* rhs1, double* x1) {
         Level& lv = *levels[l];
         Level& nx = next_of(l);
@@ -619,7 +630,11 @@ struct tf_solver {
         a.next_aos = next_aos(l) ? 1 : 0; a.crf = lv.crf.p; a.zt = lv.zt.p; a.perm = lv.perm;
         a.fold_top = fold_top() && l + 1 == levels.size() ? 1 : 0;
         a.respike = l == 0 && l1_respike ? 1 : 0;
+        // twisted while one walk direction leaves SIMDs idle -- and beyond that wherever the two
+        // launches become one with y in LDS (tfk_l1_fwd2_backsub: 8 members per GPU +2.6 %,
+        // profiles/r03_ab_runs.txt; the stiff model's y block does not fit)
         a.twist = a.respike && (l1_twist < 0 ? lv.L.Ptot <= TF_TWIST_MAX_CHUNKS : l1_twist > 0) ? 1 : 0;
+        if (a.respike && l1_twist < 0 && !a.twist) { a.twist = 1; if (!l1_twist_lds(a)) a.twist = 0; }
         a.topAinv = topAinv.p; a.topx = top.x.p;
         a.stamps = stamp_buf.n ? (unsigned long long*)stamp_buf.p + 64 * l : nullptr;
         return a;
@@ -700,18 +715,6 @@ struct tf_solver {
     // skip: that many of the last levels have been back-substituted already (1: the last level
     // inside its forward / factor kernel -- a cyclic-reduction level that folds the top block
     // in; 2: the two last levels by tfk_cr_tail)
-    // The twisted level-1 kernels that keep a walk's y in LDS (tfk_l1_fwd2_backsub, tfk_l1_solve_twist):
-    // bytes of dynamic LDS per workgroup, 0 = not for this solver / plan.  Rows = the longer half of
-    // the longest chunk (tf_twist_h of tf_kernels.h: chunks too short to split, and wide blocks, stay
-    // one-sided); sets a.ylds_rows.
-    unsigned l1_twist_lds(TfLevelArgs& a) const {
-        if (!(l1_respike && a.twist && l1_fuse_backsub && tfb::is_device_build())) return 0;
-        auto half = [&](int mI) { return (spec.mp * spec.nvar <= 6 && mI >= 4 * spec.mp) ? (mI + 1) / 2 : mI; };
-        const int mI_max = a.L.M - spec.mp;
-        a.ylds_rows = std::max(half(mI_max), a.L.rem > 0 ? half(mI_max - 1) : 0);
-        const size_t lds = (size_t)2 * a.ylds_rows * spec.nvar * 64 * sizeof(double);
-        return lds <= 64u * 1024u ? (unsigned)lds : 0u;
-    }
     void backsub_chain(const double* rhs1, double* x1, int skip) {
         for (size_t l = levels.size() - (size_t)skip; l-- > 0;) {
             TfLevelArgs a = level_args(l, rhs1, x1);
@@ -751,11 +754,7 @@ struct tf_solver {
             }
             TfLevelArgs a = level_args(l, rhs1, x1);
             unsigned gx = cdiv(a.L.Ptot, 64);
-            if (l == 0) {
-                const unsigned lds = l1_solve_twist ? l1_twist_lds(a) : 0u;
-                if (lds) launch(TFK_L1_SOLVE_TWIST, gx, 1, 128, &a, sizeof(a), lds);
-                else launch(TFK_L1_SOLVE, gx, 2, 64, &a, sizeof(a));
-            }
+            if (l == 0) launch(TFK_L1_SOLVE, gx, 2, 64, &a, sizeof(a));
             else if (levels[l]->cr) { launch(TFK_CR_FWD, (unsigned)a.L.Ptot, 1, cr_block(), &a, sizeof(a)); continue; }
             else launch(TFK_BT_RHS, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 2, 64, &a, sizeof(a));
             if (l == 0) launch(TFK_L1_ASM_RHS, gx, 1, asm_block(), &a, sizeof(a));
@@ -965,6 +964,13 @@ int tf_model_create(const tf_model_spec* spec, const void* code, size_t size, tf
     TF_API_END
 }
 
+int tf_model_add_alternate(tf_model* model, const void* code, size_t size, uint64_t kernel_mask) {
+    TF_API_BEGIN
+    require(model && code, "tf_model_add_alternate: null argument");
+    tfb::module_add_alternate(model->module, code, size, kernel_mask);
+    TF_API_END
+}
+
 void tf_model_destroy(tf_model* model) { delete model; }
 
 }  // extern "C"
@@ -997,7 +1003,6 @@ tf_solver* make_solver(tf_model* model, int64_t N, int32_t nsys, int32_t periodi
     if (const char* v = getenv("TRIFLOW_CR_TAIL")) s->cr_tail = atoi(v) != 0;
     if (const char* v = getenv("TRIFLOW_L1_FUSE_BACKSUB")) s->l1_fuse_backsub = atoi(v) != 0;
     if (const char* v = getenv("TRIFLOW_TWO_FACTORS")) s->two_slots = atoi(v) != 0;
-    if (const char* v = getenv("TRIFLOW_L1_SOLVE_TWIST")) s->l1_solve_twist = atoi(v) != 0;
     s->l1_respike = TF_RESPIKE_MODEL(sp.mp, sp.nvar) && (int64_t)N * nsys >= TF_RESPIKE_MIN_NODES;
     if (const char* v = getenv("TRIFLOW_L1_TWIST")) s->l1_twist = atoi(v) != 0 ? 1 : 0;
     if (const char* v = getenv("TRIFLOW_L1_RESPIKE"))                                   // A/B runs, tests
