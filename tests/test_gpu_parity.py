@@ -298,18 +298,18 @@ def test_config4_shard_full_size():
         return out1
     # (a) the level plan a single member gets by default is the batch's plan (chunk counts do not
     # depend on the number of members): the batch dimension only adds chunks to the same
-    # kernels, member 3 comes out bit for bit.  (One difference: a single member's 31 250 chunks
-    # leave SIMDs idle, so its re-elimination walks run in twisted form, tf_twist_h; the batch's
-    # 250 000 do not.  Same form: same bits; the default form: rounding, bound as in (b).)
+    # kernels, member 3 comes out bit for bit.  (Both run their re-elimination walks in twisted form
+    # since round 3: the batch's 250 000 chunks too, because the two launches are one there,
+    # tfk_l1_fwd2_backsub.  The one-sided form of the same solve: rounding, bound as in (b).)
+    assert np.array_equal(run(member()), out[:, e, :])
+    ref = out[:, e, :]
     os.environ["TRIFLOW_L1_TWIST"] = "0"
     try:
         single = member()
     finally:
         del os.environ["TRIFLOW_L1_TWIST"]
-    assert np.array_equal(run(single), out[:, e, :])
-    ref = out[:, e, :]
-    err = np.abs(run(member()) - ref).max() / np.abs(ref).max()
-    print("config 4 shard: member %d vs single-member solver (twisted walks) %.1e" % (e, err))
+    err = np.abs(run(single) - ref).max() / np.abs(ref).max()
+    print("config 4 shard: member %d vs single-member solver (one-sided walks) %.1e" % (e, err))
     assert err <= 3e-8, err
     # (b) another level plan (chunk walks instead of cyclic reduction above 5000 nodes):
     # another elimination order of a matrix with cond(I - gamma dt J) = 2e10,

@@ -152,10 +152,7 @@ def _compile_code_object(model, source, tag, hsaco):
         # that spill are taken from a second build of the same source at -O1 (they spill there
         # too, correctly), every other kernel keeps its -O3 build.  TRIFLOW_SPILL_GATE=object
         # restores the round-2 behaviour (the whole code object at -O1).
-        warnings.warn("triflow_amd: %d kernel(s) of the model %s need more registers than a wavefront has "
-                      "(%s spill to scratch): those kernels are built at -O1 and run slower than the "
-                      "narrow-model path (DESIGN.md, solver limits)"
-                      % (len(spilled), list(model._diff_eqs), ", ".join(spilled)), RuntimeWarning, stacklevel=3)
+        _warn_wide(model, spilled)
         alt_flags = ["-O1"] + [f for f in flags if not f.startswith("-O")]
         if os.environ.get("TRIFLOW_SPILL_GATE") == "object":
             flags, alt_flags = alt_flags, None
@@ -172,6 +169,21 @@ def _compile_code_object(model, source, tag, hsaco):
     os.replace(meta + ".%d.tmp" % os.getpid(), meta)
     os.replace(tmp, hsaco)
     evict_stale_cache()
+
+
+_warned_wide = set()
+
+
+def _warn_wide(model, kernels):
+    """Once per model and process: its wide blocks do not fit the registers of a wavefront."""
+    key = tuple(str(e) for e in model._diff_eqs)
+    if key in _warned_wide:
+        return
+    _warned_wide.add(key)
+    warnings.warn("triflow_amd: %d kernel(s) of the model %s need more registers than a wavefront has "
+                  "(%s spill to scratch): those kernels are built at -O1 and run slower than the "
+                  "narrow-model path (DESIGN.md, solver limits)"
+                  % (len(kernels), list(key), ", ".join(kernels)), RuntimeWarning, stacklevel=4)
 
 
 def alternate_of(hsaco_path):
@@ -298,6 +310,8 @@ class HipBackend:
             code = f.read()
         alt, alt_kernels = alternate_of(hsaco)
         alt_code = None
+        if alt_kernels:
+            _warn_wide(model, alt_kernels)
         if alt:
             with open(alt, "rb") as f:
                 alt_code = f.read()

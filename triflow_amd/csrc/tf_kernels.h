@@ -721,15 +721,21 @@ struct TfRowsL1 {
     struct Raw { double jv[TF_NNZ > 0 ? TF_NNZ : 1]; };
     TF_DEVICE_M void request(int i, Raw& r) const {
         // (plane base in scalar registers + a 32-bit lane offset: planes are < 4 GB, tf_solver_create)
+        // (proportional entries are filled in by decode(): scaling here would wait for the load
+        // that this request only wants to put on its way)
         const unsigned off = tf_off8(a.L, pg, i);
-        ju.row([&](int k) { return tf_ldp(a.Jv, k, a.L.plane, off); }, r.jv);
+#pragma unroll
+        for (int k = 0; k < TF_NNZ; ++k)
+            r.jv[k] = TF_JU(k) ? ju.v[k] : (TF_JA(k) ? 0.0 : tf_ldp(a.Jv, k, a.L.plane, off));
     }
     TF_DEVICE_M void decode(int i, const Raw& raw, double (&row)[2 * TF_MP + 1][TF_NVAR][TF_NVAR]) const {
 #pragma unroll
         for (int d = 0; d < TF_W; ++d) tf_blk_zero<TF_NVAR>(row[d]);
 #pragma unroll
-        for (int k = 0; k < TF_NNZ; ++k)
-            row[tf_pat_off[k] + TF_MP][tf_pat_eq[k]][tf_pat_var[k]] = -a.c * raw.jv[k];
+        for (int k = 0; k < TF_NNZ; ++k) {
+            const double jv = TF_JA(k) ? tf_j_alias_scale[k] * raw.jv[tf_j_alias[k] >= 0 ? tf_j_alias[k] : 0] : raw.jv[k];
+            row[tf_pat_off[k] + TF_MP][tf_pat_eq[k]][tf_pat_var[k]] = -a.c * jv;
+        }
         if (!a.L.periodic) {
             const int gl = start + i, gr = a.L.N - 1 - gl;
             if (gl < TF_MP) {
