@@ -439,6 +439,31 @@ def main():
                 workers = max(1, min(n4, os.cpu_count() or 1,
                                      int(psutil.virtual_memory().available // (6 << 30))))
                 config4["cpu_baseline_members"] = cpu_baseline(3, N, "ROS2", workers=workers)
+        if world == 1 and not args.plain and getattr(solver, "constant_jacobian", False):
+            # a constant-matrix model (config 2) keeps its factorisation between steps; the reference
+            # factorises in every step (schemes.py:148-149, 557): the same workload that way, so that
+            # the two rates are never confused
+            os.environ["TRIFLOW_REUSE_FACTOR"] = "0"
+            try:
+                ens_f = Ensemble(model, x, fields, pars, bool(pars["periodic"]), scheme=scheme,
+                                 device=device_index, hook=config_hook(args.config), nstate=3)
+            finally:
+                del os.environ["TRIFLOW_REUSE_FACTOR"]
+            for _ in range(args.warmup):
+                ens_f.step(dt)
+            rates = []
+            for _ in range(7):
+                ens_f.sync()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    ens_f.step(dt)
+                ens_f.sync()
+                rates.append(args.steps * len(mine) / (time.perf_counter() - t0))
+            ens_f.close()
+            out["factorising_every_step"] = {"value": float(np.median(rates)), "unit": "steps/s",
+                                             "note": "`value` above reuses the factorisation of the constant matrix "
+                                                     "(tf_set_constant_jacobian); this is the rate with one "
+                                                     "factorisation per step, as the reference does"}
         if world == 1 and args.members_per_gpu == 1 and not args.plain:
             out["scheme_api_steps_per_s"] = scheme_api_rate(model, args.config, N, scheme, dt)
         parity_failed = None

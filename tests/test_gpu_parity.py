@@ -423,6 +423,33 @@ def test_constant_matrix_reuse():
     pc.check_constant_matrix_reuse(HIP)
 
 
+@pytest.mark.parametrize("cfg,sch,N,nsys", [(3, "ROS2", 3001, 2), (5, "BDF2", 2003, 1), (2, "Theta", 3001, 1),
+                                            (1, "Theta", 200, 1), (3, "RODASPR", 40000, 1)])
+def test_walks_assemble_the_separator_rows(cfg, sch, N, nsys, monkeypatch):
+    """Below a cyclic-reduction level the level-1 walks write their halves of the separator rows
+    themselves (tf_asm_side) instead of leaving tips for tfk_l1_asm_mat / _rhs: the same products,
+    the diagonal block summed in two parts -- states equal to rounding (periodic and clamped, hook,
+    two members, scalar blocks with row exchanges, a plan with several cyclic-reduction levels)."""
+    from triflow_amd.ensemble import Ensemble
+    name, fd, pars, dt, _ = corpus.config_inputs(cfg, N)
+    m = pc.device_model(name, HIP)
+    fields = {k: np.repeat(v[None, :], nsys, axis=0) * (1 + 0.01 * np.arange(nsys))[:, None]
+              for k, v in fd.items() if k != "x"}
+    hook = pc.DEVICE_HOOKS["cfg5"] if cfg == 5 else (pc.DEVICE_HOOKS["cfg1"] if cfg == 1 else None)
+    out = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("TRIFLOW_L1_FUSE_ASM", fuse)
+        ens = Ensemble(m, fd["x"], fields, pars, bool(pars["periodic"]), scheme=sch, hook=hook, nstate=2, refine=0)
+        for _ in range(4):
+            ens.step(dt)
+        ens.sync()
+        out.append(ens.state().copy())
+        ens.close()
+    err = np.abs(out[0] - out[1]).max() / np.abs(out[1]).max()
+    print("walk-assembled separator rows vs assemble kernels, config %d %s: %.1e" % (cfg, sch, err))
+    assert np.isfinite(out[0]).all() and err <= 1e-10, err
+
+
 def test_ensemble_restart():
     pc.check_ensemble_restart(HIP)
 

@@ -216,6 +216,9 @@ struct TfLevelArgs {
     // tfk_l1_fwd2_backsub (both of the above in one launch): rows of a walk's y block in the
     // workgroup's dynamic LDS, [direction][row][b][64 lanes]
     int ylds_rows;
+    // level 1 below a cyclic-reduction level: the walks assemble the separator rows themselves
+    // (tf_asm_side: no tips in memory, no tfk_l1_asm_* launch)
+    int fuse_asm;
     double* topAinv;               // [b][b] planes over systems (TfTopArgs::Ainv)
     double* topx;                  // [sys][b]
     // diagnostic builds (-DTF_STAMPS): one workgroup writes s_memtime stamps here (else NULL)

@@ -9,6 +9,34 @@
 
 #define TF_GID ((int)(blockIdx.x * blockDim.x + threadIdx.x))
 
+// a.fuse_asm: the walks also assemble their half of the separator rows (tf_asm_side); the 64 halves
+// of a workgroup are collected in LDS and leave as whole record halves (2*b*b contiguous doubles).
+// Offered where the stage of one wavefront leaves room for four workgroups per CU (b <= 6).
+#define TF_ASM_HALF (2 * TF_B2 * TF_B2)
+#define TF_ASM_SW (TF_ASM_HALF | 1)                  // odd stride: no bank conflicts
+#define TF_FUSE_ASM_OK (TF_ASM_SW * 64 * 8 <= 40 * 1024)
+template <bool WITH_RHS>
+__device__ __forceinline__ void tfk_l1_factor_any(const TfLevelArgs& a) {
+    __shared__ double stage[TF_FUSE_ASM_OK ? 64 * TF_ASM_SW : 1];
+    __shared__ int srec[64];
+    const int lane = threadIdx.x;
+    const bool fuse = TF_FUSE_ASM_OK && a.fuse_asm;
+    double* st = fuse ? stage + lane * TF_ASM_SW : nullptr;
+    int rec = -1;
+    if (blockIdx.y == 0) tfk_chunk_body<TfRowsL1, +1, true, true, WITH_RHS>(a, TF_GID, nullptr, st, &rec);
+    else tfk_chunk_body<TfRowsL1, -1, true, TF_RESPIKE_MODEL(TF_MP, TF_NVAR), false>(a, TF_GID, nullptr, st, &rec);
+    if (fuse) {
+        srec[lane] = rec;
+        __syncthreads();
+        const int side = blockIdx.y == 0 ? 0 : TF_ASM_HALF;       // [sub, dia | sup, second part of dia]
+        for (int idx = lane; idx < 64 * TF_ASM_HALF; idx += 64) {
+            const int t = idx / TF_ASM_HALF, off = idx - t * TF_ASM_HALF;
+            const int r = srec[t];
+            if (r >= 0) a.Anext[(int64_t)r * 2 * TF_ASM_HALF + side + off] = stage[t * TF_ASM_SW + off];
+        }
+    }
+}
+
 extern "C" {
 
 // ---- stencil sweeps: block (64,1,1), grid (chunks/64, segments) ------------
@@ -139,16 +167,10 @@ __global__ void __launch_bounds__(64) tfk_poke(TfPokeArgs a) {
 
 // ---- banded solver, level 1 (rows from the Jacobian planes) ----------------
 // grid.y: 0 = walk down, 1 = walk up (wave-uniform)
-__global__ void __launch_bounds__(64) tfk_l1_factor(TfLevelArgs a) {
-    if (blockIdx.y == 0) tfk_chunk_body<TfRowsL1, +1, true, true, false>(a, TF_GID);
-    else tfk_chunk_body<TfRowsL1, -1, true, TF_RESPIKE_MODEL(TF_MP, TF_NVAR), false>(a, TF_GID);
-}
+__global__ void __launch_bounds__(64) tfk_l1_factor(TfLevelArgs a) { tfk_l1_factor_any<false>(a); }
 // factorisation that also eliminates a first right-hand side (the first solve of a
 // time step rides along: no second walk over J for it)
-__global__ void __launch_bounds__(64) tfk_l1_factor_rhs(TfLevelArgs a) {
-    if (blockIdx.y == 0) tfk_chunk_body<TfRowsL1, +1, true, true, true>(a, TF_GID);
-    else tfk_chunk_body<TfRowsL1, -1, true, TF_RESPIKE_MODEL(TF_MP, TF_NVAR), false>(a, TF_GID);
-}
+__global__ void __launch_bounds__(64) tfk_l1_factor_rhs(TfLevelArgs a) { tfk_l1_factor_any<true>(a); }
 __global__ void __launch_bounds__(64) tfk_l1_solve(TfLevelArgs a) {
     if (blockIdx.y == 0) tfk_chunk_body<TfRowsL1, +1, false, false, true>(a, TF_GID);
     else tfk_chunk_body<TfRowsL1, -1, false, false, false>(a, TF_GID);

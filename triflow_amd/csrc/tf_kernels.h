@@ -826,6 +826,17 @@ struct TfRowsBT {
 // latency but cost 2 x (nnz + nvar) registers in kernels that already overflow into AGPRs; with the
 // walks bound by their instruction stream the moves cost more than the latency:
 // one row ahead is 4 % faster on config 3 (tfk_l1_fwd2 63 -> 52 us), 2 % on config 5 / 8 members.
+// The row requests of the walks are prefetches: they must be *issued* where they are written, one
+// node ahead of their use.  TF_PIN=1 keeps the compiler from sinking them towards the use (a
+// memory clobber: loads and stores keep their side of it, the wait stays at the use).
+#ifndef TF_PIN
+#define TF_PIN 0
+#endif
+#if TF_PIN
+#define TF_PIN_REQUESTS() asm volatile("" ::: "memory")
+#else
+#define TF_PIN_REQUESTS() do {} while (0)
+#endif
 #ifndef TF_PREFETCH_DEEP
 #define TF_PREFETCH_DEEP(spike) 0
 #endif
@@ -853,6 +864,98 @@ TF_DEVICE int tf_twist_h(int mI, int enabled) {
     return (TF_TWIST && enabled && MP * B <= 6 && mI >= 4 * MP) ? (mI + 1) / 2 : mI;
 }
 
+// ---- the separator equations, assembled by the walks themselves ---------------
+// When the next level keeps records per node (cyclic reduction: [sub, dia, sup, second part of
+// dia] and a right-hand side in two parts, summed when the level loads them), the two halves
+// of a separator's row can be made where the tips are: the DOWN walk of chunk p ends next to its
+// own separator and owns the tips (V, W, y) of the nodes above it -- it writes sub, the first
+// part of dia and of the right-hand side; the UP walk of chunk p+1 ends below that separator
+// and writes sup and the second parts.  Same products as tfk_asm_body (whose sums take the two
+// sides in one pass: the diagonal block differs in the last bit), no tips in memory, no
+// tfk_l1_asm_mat / tfk_l1_asm_rhs launch (profiles/r03_ab_runs.txt).  `stage`: this lane's
+// [2][b][b] part of the record (LDS, written out as whole records by the kernel); *rec = the
+// record (node of the next level) it belongs to, -1 = none.
+template <class Rows, int DIR, bool MATRIX>
+TF_DEVICE void tf_asm_side(const TfLevelArgs& a, const Rows& own, int pg,
+                           const double (&yN)[Rows::MP][Rows::B],
+                           const double (&VN)[MATRIX ? Rows::MP : 1][MATRIX ? Rows::MP : 1][Rows::B][Rows::B],
+                           const double (&WN)[MATRIX ? Rows::MP : 1][MATRIX ? Rows::MP : 1][Rows::B][Rows::B],
+                           double* stage, int* rec) {
+    constexpr int B = Rows::B, MP = Rows::MP, W = 2 * MP + 1, BB = MP * B;
+    const TfLayout& L = a.L;
+    const int e = own.e, p = own.p;
+    const bool has = DIR > 0 || L.periodic || p > 0;
+    const int ps = DIR > 0 ? p : (p > 0 ? p - 1 : L.P - 1);      // the chunk that owns the separator
+    const int r_next = has ? e * a.Lnext.N + ps : -1;             // (Lnext.N == L.P)
+    if (rec) *rec = r_next;
+    if (!has) return;
+    const int pgs = e * L.P + ps;
+    Rows rs(a, pgs);
+    const int mIs = rs.len - MP;
+#pragma unroll
+    for (int t = 0; t < MP; ++t) {                 // separator node t = node mIs + t of chunk ps
+        double row[W][B][B];
+        rs.load(mIs + t, row);
+        double A1[MP][B][B], A2[MP][B][B], g[B];   // down: sub, dia      up: sup, second part of dia
+#pragma unroll
+        for (int t2 = 0; t2 < MP; ++t2) { tf_blk_zero<B>(A1[t2]); tf_blk_zero<B>(A2[t2]); }
+        const int64_t s = tf_idx(L, pgs, mIs + t);
+#pragma unroll
+        for (int r = 0; r < B; ++r) g[r] = (DIR > 0 && a.rhs) ? a.rhs[(int64_t)r * L.plane + s] : 0.0;
+#pragma unroll
+        for (int d = -MP; d <= MP; ++d) {
+            const int cn = t + d;                  // column relative to the separator start
+            if (DIR > 0) {
+                if (cn >= 0 && cn < MP) {
+                    if (MATRIX) {
+#pragma unroll
+                        for (int r = 0; r < B; ++r)
+#pragma unroll
+                            for (int c = 0; c < B; ++c) A2[cn][r][c] += row[d + MP][r][c];
+                    }
+                } else if (cn < 0) {               // bottom tip node kb of the own interior
+                    const int kb = cn + MP;
+                    tf_mv_sub<B>(g, row[d + MP], yN[kb]);
+                    if (MATRIX) {
+#pragma unroll
+                        for (int t2 = 0; t2 < MP; ++t2) {
+                            tf_mm_sub<B>(A1[t2], row[d + MP], VN[MATRIX ? kb : 0][MATRIX ? t2 : 0]);
+                            tf_mm_sub<B>(A2[t2], row[d + MP], WN[MATRIX ? kb : 0][MATRIX ? t2 : 0]);
+                        }
+                    }
+                }
+            } else if (cn >= MP) {                 // top tip node kt of the interior below
+                const int kt = cn - MP;
+                tf_mv_sub<B>(g, row[d + MP], yN[kt]);
+                if (MATRIX) {
+#pragma unroll
+                    for (int t2 = 0; t2 < MP; ++t2) {
+                        tf_mm_sub<B>(A2[t2], row[d + MP], VN[MATRIX ? kt : 0][MATRIX ? t2 : 0]);
+                        tf_mm_sub<B>(A1[t2], row[d + MP], WN[MATRIX ? kt : 0][MATRIX ? t2 : 0]);
+                    }
+                }
+            }
+        }
+        if (a.rhs) {
+#pragma unroll
+            for (int r = 0; r < B; ++r)
+                a.rhsnext[(int64_t)r_next * 2 * BB + (DIR > 0 ? 0 : BB) + t * B + r] = g[r];
+        }
+        if (MATRIX) {
+#pragma unroll
+            for (int t2 = 0; t2 < MP; ++t2)
+#pragma unroll
+                for (int r = 0; r < B; ++r)
+#pragma unroll
+                    for (int c = 0; c < B; ++c) {
+                        const int rr = t * B + r, cc = t2 * B + c;
+                        stage[(0 * BB + rr) * BB + cc] = A1[t2][r][c];
+                        stage[(1 * BB + rr) * BB + cc] = A2[t2][r][c];
+                    }
+        }
+    }
+}
+
 // ---- interior elimination of one chunk in one direction --------------------
 // DIR = +1 walks down (local j <-> node j), DIR = -1 walks up (local j <-> node
 // mI-1-j, offsets mirrored).  SPIKE: also carry the coupling to the separator
@@ -867,8 +970,10 @@ TF_DEVICE int tf_twist_h(int mI, int enabled) {
 // same launch).
 // (YLDS is a flag, not a null test of the pointer: testing an LDS pointer against NULL trips
 // hipcc 7.2 on some models, "Illegal instruction detected: V_CMP_NE_U32 0, $src_shared_base")
+// asm_stage / asm_rec (a.fuse_asm): where tf_asm_side puts this walk's part of a separator's row.
 template <class Rows, int DIR, bool SPIKE, bool STORE_U, bool STORE_Y, bool KNOWN = false, bool YLDS = false>
-TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg, double* ylds = nullptr) {
+TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg, double* ylds = nullptr,
+                              double* asm_stage = nullptr, int* asm_rec = nullptr) {
     constexpr int B = Rows::B, MP = Rows::MP, W = 2 * MP + 1;
     static_assert(!KNOWN || (!SPIKE && !STORE_U), "the re-elimination takes one right-hand side");
     constexpr bool PIV = Rows::PIVOT;             // row exchanges inside the window (B == 1)
@@ -964,6 +1069,7 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg, double* ylds = nullp
         install(q, jl, pre0);
         if (DEEP) { pre0 = pre1; request(jl + 2, pre1); }
         else request(jl + 1, pre0);
+        TF_PIN_REQUESTS();                           // (the loads leave here, whatever the scheduler would like)
     };
 
 #pragma unroll
@@ -1127,6 +1233,28 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg, double* ylds = nullp
         }
     }
 
+    if (!KNOWN && a.fuse_asm) {
+        // the tips in natural orientation stay in registers: this walk's half of the separator's row
+        double yN[MP][B];
+        double VN[SPIKE ? MP : 1][SPIKE ? MP : 1][B][B], WN[SPIKE ? MP : 1][SPIKE ? MP : 1][B][B];
+#pragma unroll
+        for (int k = 0; k < MP; ++k) {
+            const int kn = DIR > 0 ? k : MP - 1 - k;
+#pragma unroll
+            for (int r = 0; r < B; ++r) yN[kn][r] = yb[k][r];
+            if (SPIKE) {
+#pragma unroll
+                for (int t = 0; t < MP; ++t) {
+                    const int tn = DIR > 0 ? t : MP - 1 - t;
+                    tf_blk_copy<B>(VN[SPIKE ? kn : 0][SPIKE ? tn : 0], DIR > 0 ? Vb[SPIKE ? k : 0][SPIKE ? t : 0] : Wb[SPIKE ? k : 0][SPIKE ? t : 0]);
+                    tf_blk_copy<B>(WN[SPIKE ? kn : 0][SPIKE ? tn : 0], DIR > 0 ? Wb[SPIKE ? k : 0][SPIKE ? t : 0] : Vb[SPIKE ? k : 0][SPIKE ? t : 0]);
+                }
+            }
+        }
+        tf_asm_side<Rows, DIR, SPIKE>(a, rows, pg, yN, VN, WN, asm_stage, asm_rec);
+        if (!ok) *a.status = 1;
+        return;
+    }
     // ---- write in natural orientation
     double* tips = DIR > 0 ? a.tips_dn : a.tips_up;
     auto put = [&](int slot, double v) { tips[(int64_t)slot * L.Ptot + pg] = v; };

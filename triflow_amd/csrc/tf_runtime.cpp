@@ -552,6 +552,14 @@ struct tf_solver {
     }
     bool l1_respike = false;       // level-1 spike response not stored (tf_args.h, TF_RESPIKE_*)
     int l1_twist = -1;             // -1: by the number of chunks; 0 / 1: TRIFLOW_L1_TWIST (tests, A/B runs)
+    // level 1 below a cyclic-reduction level with b <= 6 (TF_FUSE_ASM_OK of tf_entry_hip.h): the walks
+    // assemble the separator rows, tfk_l1_asm_mat / _rhs are not launched (TRIFLOW_L1_FUSE_ASM=0: A/B)
+    bool l1_fuse_asm = true;
+    bool fuse_asm_ok() const {
+        const int b = spec.mp * spec.nvar;
+        return l1_fuse_asm && tfb::is_device_build() && levels.size() > 1 && levels[1]->cr &&
+               (2 * b * b + 1) * 64 * 8 <= 40 * 1024;
+    }
     bool l1_fuse_backsub = true;   // twisted form: tfk_l1_fwd2_backsub (TRIFLOW_L1_FUSE_BACKSUB=0: two launches)
     void stage_rhs(const double* Uin, int nterms, const double* const* ks, const double* ac,
                    const double* gc, double dt, double* y, const double* monitor_rhs) {
@@ -630,6 +638,7 @@ struct tf_solver {
         a.next_aos = next_aos(l) ? 1 : 0; a.crf = lv.crf.p; a.zt = lv.zt.p; a.perm = lv.perm;
         a.fold_top = fold_top() && l + 1 == levels.size() ? 1 : 0;
         a.respike = l == 0 && l1_respike ? 1 : 0;
+        a.fuse_asm = l == 0 && fuse_asm_ok() ? 1 : 0;
         // twisted while one walk direction leaves SIMDs idle -- and beyond that wherever the two
         // launches become one with y in LDS (tfk_l1_fwd2_backsub: 8 members per GPU +2.6 %,
         // profiles/r03_ab_runs.txt; the stiff model's y block does not fit)
@@ -682,7 +691,7 @@ struct tf_solver {
                 launch(TFK_BT_LU, gc, 2, 64, &a, sizeof(a));
                 if (G == 1) launch(TFK_BT_SPIKE, gc, 2 * (unsigned)ncols, 64, &a, sizeof(a));
             }
-            if (l == 0) launch(TFK_L1_ASM_MAT, gx, 1, asm_block(), &a, sizeof(a));
+            if (l == 0) { if (!a.fuse_asm) launch(TFK_L1_ASM_MAT, gx, 1, asm_block(), &a, sizeof(a)); }
             else launch(TFK_BT_ASM_MAT, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
         }
         if (!fold_top()) { TfTopArgs t = top_args(); launch(TFK_TOP_FACTOR, cdiv((int64_t)nsys * (tfb::coop_group(top.B) == 8 ? 8 : 1), 64), 1, 64, &t, sizeof(t)); }
@@ -757,7 +766,7 @@ struct tf_solver {
             if (l == 0) launch(TFK_L1_SOLVE, gx, 2, 64, &a, sizeof(a));
             else if (levels[l]->cr) { launch(TFK_CR_FWD, (unsigned)a.L.Ptot, 1, cr_block(), &a, sizeof(a)); continue; }
             else launch(TFK_BT_RHS, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 2, 64, &a, sizeof(a));
-            if (l == 0) launch(TFK_L1_ASM_RHS, gx, 1, asm_block(), &a, sizeof(a));
+            if (l == 0) { if (!a.fuse_asm) launch(TFK_L1_ASM_RHS, gx, 1, asm_block(), &a, sizeof(a)); }
             else launch(TFK_BT_ASM_RHS, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
         }
         if (!fold_top()) { TfTopArgs t = top_args(); launch(TFK_TOP_SOLVE, cdiv(nsys, 64), 1, 64, &t, sizeof(t)); }
@@ -1003,6 +1012,7 @@ tf_solver* make_solver(tf_model* model, int64_t N, int32_t nsys, int32_t periodi
     if (const char* v = getenv("TRIFLOW_CR_TAIL")) s->cr_tail = atoi(v) != 0;
     if (const char* v = getenv("TRIFLOW_L1_FUSE_BACKSUB")) s->l1_fuse_backsub = atoi(v) != 0;
     if (const char* v = getenv("TRIFLOW_TWO_FACTORS")) s->two_slots = atoi(v) != 0;
+    if (const char* v = getenv("TRIFLOW_L1_FUSE_ASM")) s->l1_fuse_asm = atoi(v) != 0;
     s->l1_respike = TF_RESPIKE_MODEL(sp.mp, sp.nvar) && (int64_t)N * nsys >= TF_RESPIKE_MIN_NODES;
     if (const char* v = getenv("TRIFLOW_L1_TWIST")) s->l1_twist = atoi(v) != 0 ? 1 : 0;
     if (const char* v = getenv("TRIFLOW_L1_RESPIKE"))                                   // A/B runs, tests
