@@ -160,7 +160,10 @@ __device__ __forceinline__ int tf_group8_bcast(int v) {
     // the quad that holds lane k: every lane of it takes the value (banks = quads of a 16-lane row);
     // the other quad of the group mirrors it (row_half_mirror: lane i <- lane 7 - i)
     constexpr int own = K < 4 ? 0x5 : 0xA, other = K < 4 ? 0xA : 0x5;
-    int t = __builtin_amdgcn_update_dpp(0, v, qp, 0xF, own, false);
+    // (the first move writes every lane -- the quad without lane k takes a value the mirror
+    // replaces -- so that it needs no previous value of its destination: one instruction, no zeroing)
+    (void)own;
+    int t = __builtin_amdgcn_update_dpp(0, v, qp, 0xF, 0xF, true);
     return __builtin_amdgcn_update_dpp(t, t, 0x141, 0xF, other, false);
 }
 template <int K>

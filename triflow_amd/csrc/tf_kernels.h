@@ -827,10 +827,10 @@ struct TfRowsBT {
 // walks bound by their instruction stream the moves cost more than the latency:
 // one row ahead is 4 % faster on config 3 (tfk_l1_fwd2 63 -> 52 us), 2 % on config 5 / 8 members.
 // The row requests of the walks are prefetches: they must be *issued* where they are written, one
-// node ahead of their use.  TF_PIN=1 keeps the compiler from sinking them towards the use (a
+// node ahead of their use.  TF_PIN keeps the compiler from sinking them towards the use (a
 // memory clobber: loads and stores keep their side of it, the wait stays at the use).
 #ifndef TF_PIN
-#define TF_PIN 0
+#define TF_PIN 1                   // (config 3 +0.5 %, config 5 +3 %, 8 members +0.4 %: profiles/r03_ab_runs.txt)
 #endif
 #if TF_PIN
 #define TF_PIN_REQUESTS() asm volatile("" ::: "memory")
