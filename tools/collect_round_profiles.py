@@ -20,13 +20,18 @@ def last_line(src, name):
 
 last_line(os.path.join(out, "bench.json"), prefix + "_bench.json")
 for n in ("config5", "config2", "members8", "rodaspr"):
-    last_line(os.path.join(out, "bench_%s.json" % n), "%s_bench_%s.json" % (prefix, n))
+    try:
+        last_line(os.path.join(out, "bench_%s.json" % n), "%s_bench_%s.json" % (prefix, n))
+    except (OSError, ValueError, IndexError) as ex:
+        print("no %s line: %s" % (n, ex))
 shutil.copy(os.path.join(prof, "kernel_stats.csv"), os.path.join(dst, prefix + "_bench_kernel_stats.csv"))
 shutil.copy(os.path.join(prof, "pmc_summary.json"), os.path.join(dst, prefix + "_bench_pmc_summary.json"))
 shutil.copy(os.path.join(prof, "bench_under_rocprof.json"), os.path.join(dst, prefix + "_bench_under_rocprof.json"))
 shutil.copy(os.path.join(ctr, "sq_summary.json"), os.path.join(dst, prefix + "_sq_counters.json"))
 shutil.copy(os.path.join(out, "levels.txt"), os.path.join(dst, prefix + "_solver_levels_trace.txt"))
 shutil.copy(os.path.join(out, "step_doubling_trial.txt"), os.path.join(dst, prefix + "_step_doubling_trial.txt"))
+if os.path.exists(os.path.join(out, "stamps.txt")):
+    shutil.copy(os.path.join(out, "stamps.txt"), os.path.join(dst, prefix + "_cr_factor_stamps.txt"))
 p = json.load(open(os.path.join(prof, "pmc_summary.json")))
 s = p["tfk_sweep_fj"]
 t = json.load(open(os.path.join(dst, "sweep_traffic.json")))

@@ -41,10 +41,14 @@ for cfg in (2, 3):
         e = max(schemes._difference_norms(coarse, fields, 2)) / 99
         return fields, e
     g2, e2 = python_trial(f)
+    c0 = solver.counters()
     t0 = time.perf_counter()
     for _ in range(ntr):
         g2, e2 = python_trial(g2)
     py = (time.perf_counter() - t0) / ntr
+    c1 = solver.counters()
+    print("   the %d trials driven from Python made %d factorisation(s) and %d synchronising check(s)"
+          % (ntr, c1["factorisations"] - c0["factorisations"], c1["checks"] - c0["checks"]), flush=True)
     print("config %d (%s, N=%d): fixed step %.3f ms -> 11 steps %.3f ms; step-doubling trial: fused %.3f ms "
           "(%.2f x 11 steps), driven from Python %.3f ms (%.2f x)"
           % (cfg, sch, fd["x"].size, fixed * 1e3, 11 * fixed * 1e3, fused * 1e3, fused / (11 * fixed),

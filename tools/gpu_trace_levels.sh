@@ -5,7 +5,7 @@ set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/trace_levels
 rm -rf $OUT && mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench.log 2>&1
+python3 /opt/rocm/bin/rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 agg = collections.defaultdict(list)

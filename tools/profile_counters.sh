@@ -10,7 +10,7 @@ mkdir -p $OUT
 ARGS="--steps 4 --warmup 1 --repeats 25 --no-cpu-baseline --plain $*"
 pass() {   # name, counters...
     local name=$1; shift
-    rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py $ARGS > $OUT/$name.log 2>&1 \
+    python3 /opt/rocm/bin/rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py $ARGS > $OUT/$name.log 2>&1 \
         || { echo "pass $name failed"; tail -5 $OUT/$name.log; }
     echo "pass $name done" >> $OUT/progress.txt
 }

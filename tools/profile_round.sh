@@ -5,9 +5,9 @@ set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$1
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 20 --warmup 3 --repeats 5 --no-cpu-baseline > $OUT/bench_trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 5 --warmup 1 --repeats 1 --plain --no-cpu-baseline > $OUT/bench_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 5 --warmup 1 --repeats 1 --plain --no-cpu-baseline > $OUT/bench_write.log 2>&1
+python3 /opt/rocm/bin/rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 20 --warmup 3 --repeats 5 --no-cpu-baseline > $OUT/bench_trace.log 2>&1
+python3 /opt/rocm/bin/rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 5 --warmup 1 --repeats 1 --plain --no-cpu-baseline > $OUT/bench_fetch.log 2>&1
+python3 /opt/rocm/bin/rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 5 --warmup 1 --repeats 1 --plain --no-cpu-baseline > $OUT/bench_write.log 2>&1
 python3 - <<PY
 import csv, glob, collections, json
 out = "$OUT"

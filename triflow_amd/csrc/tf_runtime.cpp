@@ -907,12 +907,15 @@ struct tf_solver {
     // synchronisation); with refine = -2 every step does.  The worst value since the last look is
     // read here, at the synchronising calls.
     bool monitored = false;
-    void check_status() {
+    // have_flag / have_worst: values that already came back with another download of this call
+    void check_status(const int* have_flag = nullptr, const double* have_worst = nullptr) {
         int flag = 0;
-        tfb::d2h(&flag, status, sizeof(int), stream);
+        if (have_flag) flag = *have_flag;
+        else tfb::d2h(&flag, status, sizeof(int), stream);
         if (monitored) {
             double worst = 0.0;
-            tfb::d2h(&worst, red.p + 4, sizeof(double), stream);
+            if (have_worst) worst = *have_worst;
+            else tfb::d2h(&worst, red.p + 4, sizeof(double), stream);
             tfb::memset0(red.p + 4, sizeof(double), stream);
             monitored = false;
             if (worst > refine_trigger || worst != worst) {
@@ -1467,16 +1470,27 @@ void step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns, con
 }
 
 // per system and variable ||state[a] - state[b]||_ord (ord 2 / 0 = max), out[nsys][nvar]
-void diff_norm(tf_solver* s, int32_t slot_a, int32_t slot_b, int32_t ord, double* out) {
+// with_status: the device-side failure flag and the monitor's worst value come back in the same
+// download (one host wait for a whole step-doubling trial) and are looked at like tf_sync does
+void diff_norm(tf_solver* s, int32_t slot_a, int32_t slot_b, int32_t ord, double* out, bool with_status = false) {
     require(ord == 0 || ord == 2, "tf_diff_norm: ord must be 2 or 0 (max norm)");
     const int nb = 64, nvs = s->spec.nvar * s->nsys;
-    if (s->normbuf.n < (size_t)nb * nvs) s->normbuf.alloc((size_t)nb * nvs, s->bytes);
+    if (s->normbuf.n < (size_t)nb * nvs + 2) s->normbuf.alloc((size_t)nb * nvs + 2, s->bytes);
     TfNormArgs a;
     a.L = s->L1; a.a = s->st(slot_a); a.b = s->st(slot_b); a.partial = s->normbuf.p;
     a.nblocks = nb; a.ord = ord;
     s->launch(TFK_DIFFNORM, nb, nvs, 256, &a, sizeof(a));
-    std::vector<double> part((size_t)nb * nvs);
-    tfb::d2h(part.data(), s->normbuf.p, part.size() * sizeof(double), s->stream);
+    std::vector<double> part((size_t)nb * nvs + 2);
+    if (with_status) {
+        tfb::d2d(s->normbuf.p + (size_t)nb * nvs, s->status, sizeof(int), s->stream);
+        tfb::d2d(s->normbuf.p + (size_t)nb * nvs + 1, s->red.p + 4, sizeof(double), s->stream);
+    }
+    tfb::d2h(part.data(), s->normbuf.p, ((size_t)nb * nvs + (with_status ? 2 : 0)) * sizeof(double), s->stream);
+    if (with_status) {
+        int flag = 0;
+        std::memcpy(&flag, &part[(size_t)nb * nvs], sizeof(int));
+        s->check_status(&flag, &part[(size_t)nb * nvs + 1]);
+    }
     for (int vs = 0; vs < nvs; ++vs) {                 // fixed order: deterministic
         double acc = 0.0;
         for (int b = 0; b < nb; ++b) {
@@ -1562,7 +1576,7 @@ int tf_step_doubling(tf_solver* s, int32_t src, int32_t dst, int32_t tmp, int32_
         from = to;
     }
     std::vector<double> norms((size_t)s->nsys * s->spec.nvar);
-    diff_norm(s, coarse, dst, ord, norms.data());                  // the one synchronisation
+    diff_norm(s, coarse, dst, ord, norms.data(), true);            // the one synchronisation (norms + status)
     for (int e = 0; e < s->nsys; ++e) {
         double worst = 0.0;
         for (int v = 0; v < s->spec.nvar; ++v) {
@@ -1571,7 +1585,6 @@ int tf_step_doubling(tf_solver* s, int32_t src, int32_t dst, int32_t tmp, int32_
         }
         err_out[e] = worst / ((double)m * m - 1.0);
     }
-    s->check_status();
     TF_API_END
 }
 
