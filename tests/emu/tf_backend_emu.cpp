@@ -142,6 +142,10 @@ void launch(Module*, int kernel, unsigned gx, unsigned gy, unsigned block,
         for (int64_t t = 0; t < nthreads; ++t) tfk_top_body<TF_B2, true>(a, (int)t); } break;
     case TFK_TOP_SOLVE: { const auto& a = *(const TfTopArgs*)args;
         for (int64_t t = 0; t < nthreads; ++t) tfk_top_body<TF_B2, false>(a, (int)t); } break;
+    case TFK_TINY_FACTOR: { const auto& a = *(const TfTinyArgs*)args;
+        for (int64_t t = 0; t < nthreads; ++t) tfk_tiny_factor_body(a, (int)t); } break;
+    case TFK_TINY_SOLVE: { const auto& a = *(const TfTinyArgs*)args;
+        for (int64_t t = 0; t < nthreads; ++t) tfk_tiny_solve_body(a, (int)t); } break;
     default: throw std::runtime_error("emu: unknown kernel");
     }
 }

@@ -82,6 +82,33 @@ def check_FJ_bitexact_large(name, backend, N):
 
 
 # ---------------------------------------------------------------- seam #3: solver
+def check_tiny_grids(backend):
+    """Grids shorter than one stencil window (N < 2*mp + 1): the reference pads them with ghost cells
+    that wrap or clamp onto nodes already in the window (compilers.py:257-264) and hands SuperLU the small
+    dense system.  F bit for bit, J to the order of the duplicate sums, one Theta and one ROS2 step
+    (the dense path tfk_tiny_*) against the oracle."""
+    cases = [("M1_advdiff", 2, True), ("M1_advdiff", 2, False), ("M1_advdiff", 1, False),
+             ("kdv", 2, True), ("kdv", 3, True), ("kdv", 4, False), ("kdv", 3, False),
+             ("M3_film", 3, True), ("M3_film", 4, True), ("M3_film", 4, False), ("M3_film", 2, False)]
+    for name, N, periodic in cases:
+        m, mo = device_model(name, backend), oracle_model(name)
+        fd = corpus.synthetic_fields(name, max(N, 2), seed=4, periodic=periodic, length=0.5 * max(N, 2))
+        if N == 1:
+            # (dx from a one-node grid is 0/0 in the reference, compilers.py:234-237: skip the degenerate spacing)
+            continue
+        pars = corpus.synthetic_pars(name, N, periodic)
+        F, Fo = m.F(m.fields_template(**fd), pars), mo.F(mo.fields_template(**fd), pars)
+        assert np.array_equal(F, Fo), (name, N, periodic)
+        J, Jo = m.J(m.fields_template(**fd), pars), mo.J(mo.fields_template(**fd), pars)
+        assert np.array_equal(J.indptr, Jo.indptr) and np.array_equal(J.indices, Jo.indices)
+        assert (np.abs(J.data - Jo.data) <= 4 * np.spacing(np.abs(Jo.data).max())).all(), (name, N, periodic)
+        for sd, so in ((schemes.Theta(m), ora.Theta(mo)), (schemes.ROS2(m), ora.ROS2(mo))):
+            _, fdv = sd(0.0, m.fields_template(**fd), 1e-2, pars)
+            _, fov = so(0.0, mo.fields_template(**fd), 1e-2, pars)
+            err = np.abs(fdv.uflat - fov.uflat).max() / np.abs(fov.uflat).max()
+            assert err <= 1e-11, (name, N, periodic, type(sd).__name__, err)
+
+
 def check_proportional_entries(backend):
     """Jacobian entries that the generated code marks as a power-of-two multiple of another entry
     (codegen._proportional_entries: the solver walks, J @ v and the monitors load one and scale)

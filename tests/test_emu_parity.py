@@ -51,6 +51,10 @@ def test_steps_golden_python_hook(backend):
                           only=("Theta1", "ROS2", "RODASPR_adapt"))
 
 
+def test_tiny_grids(backend):
+    pc.check_tiny_grids(backend)
+
+
 def test_proportional_entries(backend):
     pc.check_proportional_entries(backend)
 

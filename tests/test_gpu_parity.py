@@ -95,6 +95,10 @@ def test_steps_golden_python_hook(case):
                           only=("Theta1", "ROS2", "RODASPR", "ROS3PRw_adapt"))
 
 
+def test_tiny_grids():
+    pc.check_tiny_grids(HIP)
+
+
 def test_proportional_entries():
     pc.check_proportional_entries(HIP)
 

@@ -225,6 +225,23 @@ struct TfLevelArgs {
     unsigned long long* stamps;
 };
 
+// Grids shorter than one stencil window (N < 2*mp + 1): the ghost cells of compilers.py:257-264 wrap
+// or clamp onto nodes that are already in the window, the matrix I - cJ is small and dense.  One
+// thread per system assembles it (duplicate columns summed, like csc_matrix() does), factorises it
+// with partial pivoting and solves (tfk_tiny_factor / tfk_tiny_solve).
+struct TfTinyArgs {
+    TfLayout L;                    // one chunk per system (P == 1)
+    const double* Jv;
+    const double* parsca;
+    const double* dx;
+    double c;
+    double* lu;                    // [nsys][n][n], n = N * nvar
+    int* piv;                      // [nsys][n]
+    const double* rhs;             // [nvar] planes
+    double* x;                     // [nvar] planes
+    int* status;
+};
+
 struct TfTailArgs {                // tfk_cr_tail: the last two cyclic-reduction levels of a solve in one launch
     TfLevelArgs lv[2];
 };
@@ -267,7 +284,7 @@ enum TfKernel {
     TFK_BT_LU, TFK_BT_SPIKE, TFK_BT_RHS, TFK_BT_ASM_MAT, TFK_BT_ASM_RHS, TFK_BT_BACKSUB,
     TFK_TOP_FACTOR, TFK_TOP_SOLVE, TFK_BERR, TFK_DIFFNORM, TFK_L1_FACTOR_RHS, TFK_SWEEP_F_STAGE,
     TFK_CR_FACTOR, TFK_CR_FWD, TFK_CR_BWD, TFK_POKE, TFK_SWEEP_FJ_THETA, TFK_SWEEP_FJ_BDF2, TFK_SPMV_MON, TFK_GATHER,
-    TFK_SWEEP_F_STAGE_RHS, TFK_L1_FWD2, TFK_L1_BACKSUB_U, TFK_CR_TAIL, TFK_L1_FWD2_BACKSUB, TFK_COUNT
+    TFK_SWEEP_F_STAGE_RHS, TFK_L1_FWD2, TFK_L1_BACKSUB_U, TFK_CR_TAIL, TFK_L1_FWD2_BACKSUB, TFK_TINY_FACTOR, TFK_TINY_SOLVE, TFK_COUNT
 };
 #define TF_KERNEL_NAMES { \
     "tfk_sweep_f", "tfk_sweep_fj", "tfk_spmv", "tfk_vec", "tfk_vec_maxabs", "tfk_perm", "tfk_dirichlet", \
@@ -276,4 +293,4 @@ enum TfKernel {
     "tfk_top_factor", "tfk_top_solve", "tfk_berr", "tfk_diffnorm", "tfk_l1_factor_rhs", "tfk_sweep_f_stage", \
     "tfk_cr_factor", "tfk_cr_fwd", "tfk_cr_bwd", "tfk_poke", "tfk_sweep_fj_theta", "tfk_sweep_fj_bdf2", \
     "tfk_spmv_mon", "tfk_gather", "tfk_sweep_f_stage_rhs", "tfk_l1_fwd2", "tfk_l1_backsub_u", "tfk_cr_tail", \
-    "tfk_l1_fwd2_backsub" }
+    "tfk_l1_fwd2_backsub", "tfk_tiny_factor", "tfk_tiny_solve" }

@@ -278,6 +278,9 @@ __global__ void __launch_bounds__(64) tfk_top_factor(TfTopArgs a) {
     else tfk_top_body<TF_B2, true>(a, TF_GID);
 }
 __global__ void __launch_bounds__(64) tfk_top_solve(TfTopArgs a) { tfk_top_body<TF_B2, false>(a, TF_GID); }
+// grids shorter than one stencil window: a thread per system (TfTinyArgs)
+__global__ void __launch_bounds__(64) tfk_tiny_factor(TfTinyArgs a) { tfk_tiny_factor_body(a, TF_GID); }
+__global__ void __launch_bounds__(64) tfk_tiny_solve(TfTinyArgs a) { tfk_tiny_solve_body(a, TF_GID); }
 
 // ---- cyclic-reduction levels (tf_coop_hip.h): 3 <= b <= 8 one wavefront per 16-node chunk
 //      (8 lanes per node); b <= 2 one thread per node, 256-node chunks

@@ -1833,6 +1833,70 @@ TF_DEVICE void tfk_backsub_twist_body(const TfLevelArgs& a, int pg, int dir,
     }
 }
 
+// ---- grids shorter than one stencil window: dense, one thread per system -----------
+#define TF_TINY_MAXN (2 * TF_MP * TF_NVAR)        // N <= 2*mp nodes
+TF_DEVICE void tfk_tiny_factor_body(const TfTinyArgs& a, int e) {
+    const TfLayout& L = a.L;
+    if (e >= L.nsys) return;
+    const int N = L.N, n = N * TF_NVAR;
+    double* A = a.lu + (int64_t)e * n * n;
+    int* piv = a.piv + (int64_t)e * n;
+    for (int i = 0; i < n * n; ++i) A[i] = 0.0;
+    TfJUniform ju;
+    ju.init(a.parsca, a.dx, L.nsys, e);
+    for (int i = 0; i < N; ++i) {
+        const int64_t s = tf_idx(L, e, i);             // (P == 1: chunk index = system index)
+        double jr[TF_NNZ > 0 ? TF_NNZ : 1];
+        ju.row([&](int k) { return a.Jv[(int64_t)k * L.plane + s]; }, jr);
+        for (int k = 0; k < TF_NNZ; ++k) {
+            int j = i + tf_pat_off[k];
+            if (L.periodic) j = ((j % N) + N) % N;
+            else j = j < 0 ? 0 : (j > N - 1 ? N - 1 : j);
+            A[(i * TF_NVAR + tf_pat_eq[k]) * n + j * TF_NVAR + tf_pat_var[k]] += -a.c * jr[k];
+        }
+        for (int v = 0; v < TF_NVAR; ++v) A[(i * TF_NVAR + v) * (n + 1)] += 1.0;
+    }
+    bool ok = true;
+    for (int k = 0; k < n; ++k) {                      // LU with partial pivoting, in place
+        int p = k;
+        for (int r = k + 1; r < n; ++r) if (tf_abs(A[r * n + k]) > tf_abs(A[p * n + k])) p = r;
+        piv[k] = p;
+        if (p != k)
+            for (int c2 = 0; c2 < n; ++c2) { const double t = A[k * n + c2]; A[k * n + c2] = A[p * n + c2]; A[p * n + c2] = t; }
+        const double d = A[k * n + k];
+        ok = ok && d != 0.0 && tf_finite(d);
+        const double rd = 1.0 / d;
+        for (int r = k + 1; r < n; ++r) {
+            const double f = A[r * n + k] * rd;
+            A[r * n + k] = f;
+            for (int c2 = k + 1; c2 < n; ++c2) A[r * n + c2] = tf_fma(-f, A[k * n + c2], A[r * n + c2]);
+        }
+    }
+    if (!ok) *a.status = 1;
+}
+TF_DEVICE void tfk_tiny_solve_body(const TfTinyArgs& a, int e) {
+    const TfLayout& L = a.L;
+    if (e >= L.nsys) return;
+    const int N = L.N, n = N * TF_NVAR;
+    const double* A = a.lu + (int64_t)e * n * n;
+    const int* piv = a.piv + (int64_t)e * n;
+    double y[TF_TINY_MAXN];
+    for (int i = 0; i < N; ++i)
+        for (int v = 0; v < TF_NVAR; ++v) y[i * TF_NVAR + v] = a.rhs[(int64_t)v * L.plane + tf_idx(L, e, i)];
+    for (int k = 0; k < n; ++k) {
+        const int p = piv[k];
+        if (p != k) { const double t = y[k]; y[k] = y[p]; y[p] = t; }
+        for (int r = k + 1; r < n; ++r) y[r] = tf_fma(-A[r * n + k], y[k], y[r]);
+    }
+    for (int k = n - 1; k >= 0; --k) {
+        double acc = y[k];
+        for (int c2 = k + 1; c2 < n; ++c2) acc = tf_fma(-A[k * n + c2], y[c2], acc);
+        y[k] = acc / A[k * n + k];
+    }
+    for (int i = 0; i < N; ++i)
+        for (int v = 0; v < TF_NVAR; ++v) a.x[(int64_t)v * L.plane + tf_idx(L, e, i)] = y[i * TF_NVAR + v];
+}
+
 // ---- last level: one b x b block per system ---------------------------------
 template <int BB, bool FACTOR>
 TF_DEVICE void tfk_top_body(const TfTopArgs& a, int e) {

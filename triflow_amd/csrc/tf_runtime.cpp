@@ -333,6 +333,7 @@ struct tf_solver {
         if (dir_var) tfb::dev_free(dir_var);
         if (dir_node) tfb::dev_free(dir_node);
         delete fallback;
+        if (tiny_piv) tfb::dev_free(tiny_piv);
         if (owns_stream) tfb::stream_destroy(stream);
     }
 
@@ -560,6 +561,17 @@ struct tf_solver {
         return l1_fuse_asm && tfb::is_device_build() && levels.size() > 1 && levels[1]->cr &&
                (2 * b * b + 1) * 64 * 8 <= 40 * 1024;
     }
+    // N < 2*mp + 1: dense factorisation, one thread per system (tfk_tiny_*)
+    bool tiny = false;
+    DevBuf tiny_lu;
+    int* tiny_piv = nullptr;
+    TfTinyArgs tiny_args(const double* rhs1, double* x1) {
+        TfTinyArgs t;
+        std::memset(&t, 0, sizeof(t));
+        t.L = L1; t.Jv = Jv.p; t.parsca = parsca.p; t.dx = dx.p; t.c = factor_c;
+        t.lu = tiny_lu.p; t.piv = tiny_piv; t.rhs = rhs1; t.x = x1; t.status = status;
+        return t;
+    }
     bool l1_fuse_backsub = true;   // twisted form: tfk_l1_fwd2_backsub (TRIFLOW_L1_FUSE_BACKSUB=0: two launches)
     void stage_rhs(const double* Uin, int nterms, const double* const* ks, const double* ac,
                    const double* gc, double dt, double* y, const double* monitor_rhs) {
@@ -672,8 +684,12 @@ struct tf_solver {
             if (rhs1) delegate_solve(rhs1, x1);
             return;
         }
-        const bool fused = rhs1 != nullptr;
-        for (size_t l = 0; l < levels.size(); ++l) {
+        const bool fused = rhs1 != nullptr && !tiny;
+        if (tiny) {
+            TfTinyArgs t = tiny_args(nullptr, nullptr);
+            launch(TFK_TINY_FACTOR, cdiv(nsys, 64), 1, 64, &t, sizeof(t));
+        }
+        for (size_t l = 0; l < levels.size() && !tiny; ++l) {
             TfLevelArgs a = level_args(l, rhs1, x1);
             if (!fused) a.rhs = nullptr;
             unsigned gx = cdiv(a.L.Ptot, 64);
@@ -694,7 +710,7 @@ struct tf_solver {
             if (l == 0) { if (!a.fuse_asm) launch(TFK_L1_ASM_MAT, gx, 1, asm_block(), &a, sizeof(a)); }
             else launch(TFK_BT_ASM_MAT, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
         }
-        if (!fold_top()) { TfTopArgs t = top_args(); launch(TFK_TOP_FACTOR, cdiv((int64_t)nsys * (tfb::coop_group(top.B) == 8 ? 8 : 1), 64), 1, 64, &t, sizeof(t)); }
+        if (!fold_top() && !tiny) { TfTopArgs t = top_args(); launch(TFK_TOP_FACTOR, cdiv((int64_t)nsys * (tfb::coop_group(top.B) == 8 ? 8 : 1), 64), 1, 64, &t, sizeof(t)); }
         have_factor = true;
         ++n_factor;
         cf_valid = jconst; cf_c = c; cf_ver = par_ver;
@@ -751,6 +767,11 @@ struct tf_solver {
                levels[n - 1]->L.P == 1 && levels[n - 2]->L.P <= 8;      // TF_CR_TAIL_MAXB, TF_CR_TAIL_WAVES
     }
     void solve_once(const double* rhs1, double* x1) {
+        if (tiny) {
+            TfTinyArgs t = tiny_args(rhs1, x1);
+            launch(TFK_TINY_SOLVE, cdiv(nsys, 64), 1, 64, &t, sizeof(t));
+            return;
+        }
         const bool tail = tail_ok();
         for (size_t l = 0; l < levels.size(); ++l) {
             if (tail && l + 2 == levels.size()) {
@@ -821,7 +842,7 @@ struct tf_solver {
     int m1_used = 0, mup_used = 0;
     bool delegated = false;        // the factorisation in memory lives in `fallback`
     bool replan_on = true;         // (TRIFLOW_REPLAN=0: tests of the refusal itself)
-    bool can_replan() const { return replan_on && refine == -1 && !levels.empty() && levels[0]->L.P > 1; }
+    bool can_replan() const { return replan_on && refine == -1 && !tiny && !levels.empty() && levels[0]->L.P > 1; }
     tf_solver* ensure_fallback();
     void transfer_to(tf_solver* dst, const double* src_planes, double* dst_planes, int ncomp) {
         ensure_staging((size_t)ncomp * nsys * N);
@@ -993,7 +1014,9 @@ tf_solver* make_solver(tf_model* model, int64_t N, int32_t nsys, int32_t periodi
     require(model != nullptr, "tf_solver_create: null argument");
     const tf_model_spec& sp = model->spec;
     require(nsys >= 1, "tf_solver_create: nsys must be >= 1");
-    require(N >= 2 * sp.mp + 1, "tf_solver_create: the grid must hold at least one stencil window (N >= 2*mp+1)");
+    // (shorter than one stencil window: the dense path, TfTinyArgs; periodic ghost cells need mp nodes
+    // to copy from, compilers.py:257-260)
+    require(N >= (periodic ? sp.mp : 1), "tf_solver_create: a periodic grid needs at least mp nodes");
     require(N * (int64_t)nsys < (int64_t)1 << 31, "tf_solver_create: too many nodes for 32-bit chunk indices");
     std::unique_ptr<tf_solver> s(new tf_solver());
     s->model = model; s->spec = sp; s->N = N; s->nsys = nsys; s->periodic = periodic ? 1 : 0;
@@ -1042,6 +1065,7 @@ tf_solver* make_solver(tf_model* model, int64_t N, int32_t nsys, int32_t periodi
     }
     m1 = std::max(m1, 2 * sp.mp);
     s->m1_used = m1; s->mup_used = mup;
+    s->tiny = N < 2 * sp.mp + 1;
     {
         // Reduced levels: cyclic reduction inside 16-node chunks wherever the back end has the
         // kernels for this block size (b <= 8).  Round 1 kept the chunk walks (tfk_bt_*) for levels
@@ -1095,6 +1119,11 @@ tf_solver* make_solver(tf_model* model, int64_t N, int32_t nsys, int32_t periodi
     for (size_t l = 0; l < s->levels.size(); ++l) s->levels[l]->alloc(l, nsys, s->l1_respike, tot);
     s->top.alloc_top(b2, nsys, tot);
     s->topAinv.alloc((size_t)b2 * b2 * nsys, tot);
+    if (s->tiny) {
+        const size_t n = (size_t)N * sp.nvar;
+        s->tiny_lu.alloc(n * n * nsys, tot);
+        s->tiny_piv = (int*)tfb::dev_alloc(n * nsys * sizeof(int));
+    }
     return s.release();
 }
 }  // namespace
