@@ -20,7 +20,7 @@ BUILD = os.path.join(HERE, "_build")
 
 def _deps_stamp():
     parts = []
-    for d, names in ((CSRC, ("tf_args.h", "tf_math.h", "tf_kernels.h", "tf_runtime.cpp",
+    for d, names in ((CSRC, ("tf_args.h", "tf_math.h", "tf_kernels.h", "tf_crs.h", "tf_runtime.cpp",
                              "tf_backend.h")),
                      (HERE, ("tf_backend_emu.cpp",)),
                      (os.path.join(ROOT, "include"), ("triflow_hip.h",))):

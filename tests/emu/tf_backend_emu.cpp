@@ -20,6 +20,8 @@ using std::acos; using std::log10; using std::log2; using std::cbrt; using std::
 using std::floor; using std::ceil;
 #include TF_EMU_MODEL_HEADER
 #include "tf_kernels.h"
+#include "tf_crs.h"
+#include <string>
 
 namespace tfb {
 
@@ -29,7 +31,15 @@ struct Event { int dummy; };
 
 bool is_device_build() { return false; }
 int coop_group(int) { return 1; }
-bool cyclic_reduction(int) { return false; }   // HIP only (wave-cooperative)
+// The cyclic-reduction levels run here with the one-thread-per-node kernels of tf_crs.h, one
+// "thread" taking every node in turn (the wave-cooperative kernels for 3 <= b <= 8 are HIP only):
+// record formats, two-part right-hand sides, folded top block, the walks' assembled separator rows.
+// TRIFLOW_REDUCED=walk: chunk walks on the reduced levels, as on the GPU.
+bool cyclic_reduction(int b) {
+    const char* mode = std::getenv("TRIFLOW_REDUCED");
+    if (mode && std::string(mode) == "walk") return false;
+    return b >= 1 && b <= 8;
+}
 int device_count() { return 0; }
 void set_device(int) {}
 void* dev_alloc(size_t bytes) { void* p = std::calloc(bytes ? bytes : 8, 1); if (!p) throw std::bad_alloc(); return p; }
@@ -103,10 +113,19 @@ void launch(Module*, int kernel, unsigned gx, unsigned gy, unsigned block,
         for (int64_t t = 0; t < nthreads; ++t) tfk_poke_elem(a, (int)t); } break;
     case TFK_DIRICHLET: { const auto& a = *(const TfDirichletArgs*)args;
         for (int64_t t = 0; t < nthreads; ++t) tfk_dirichlet_elem(a, (int)t); } break;
+// (a.fuse_asm: the walk leaves its half of a separator's record in `stage`, written out here)
 #define TF_EMU_CHUNK(ID, ROWS, SP, SU, SY)                                              \
     case ID: { const auto& a = *(const TfLevelArgs*)args;                               \
-        for (int64_t t = 0; t < nthreads; ++t) tfk_chunk_body<ROWS, +1, SP, SU, SY>(a, (int)t); \
-        for (int64_t t = 0; t < nthreads; ++t) tfk_chunk_body<ROWS, -1, SP, SU && TF_RESPIKE_MODEL(TF_MP, TF_NVAR), false>(a, (int)t); } break;
+        constexpr int HALF = 2 * TF_B2 * TF_B2;                                          \
+        for (int dir = 0; dir < 2; ++dir)                                                \
+            for (int64_t t = 0; t < nthreads; ++t) {                                     \
+                double stage[HALF];                                                      \
+                int rec = -1;                                                            \
+                if (dir == 0) tfk_chunk_body<ROWS, +1, SP, SU, SY>(a, (int)t, nullptr, stage, &rec); \
+                else tfk_chunk_body<ROWS, -1, SP, SU && TF_RESPIKE_MODEL(TF_MP, TF_NVAR), false>(a, (int)t, nullptr, stage, &rec); \
+                if (SP && a.fuse_asm && rec >= 0)                                        \
+                    for (int i = 0; i < HALF; ++i) a.Anext[(int64_t)rec * 2 * HALF + dir * HALF + i] = stage[i]; \
+            } } break;
     TF_EMU_CHUNK(TFK_L1_FACTOR, TfRowsL1, true, true, false)
     TF_EMU_CHUNK(TFK_L1_SOLVE, TfRowsL1, false, false, true)
     TF_EMU_CHUNK(TFK_L1_FACTOR_RHS, TfRowsL1, true, true, true)
@@ -142,6 +161,12 @@ void launch(Module*, int kernel, unsigned gx, unsigned gy, unsigned block,
         for (int64_t t = 0; t < nthreads; ++t) tfk_top_body<TF_B2, true>(a, (int)t); } break;
     case TFK_TOP_SOLVE: { const auto& a = *(const TfTopArgs*)args;
         for (int64_t t = 0; t < nthreads; ++t) tfk_top_body<TF_B2, false>(a, (int)t); } break;
+    case TFK_CR_FACTOR: { const auto& a = *(const TfLevelArgs*)args;
+        if constexpr (TF_B2 <= 8) for (unsigned c = 0; c < gx; ++c) tfk_crs_factor<TF_B2, 1>(a, (int)c, 0); } break;
+    case TFK_CR_FWD: { const auto& a = *(const TfLevelArgs*)args;
+        if constexpr (TF_B2 <= 8) for (unsigned c = 0; c < gx; ++c) tfk_crs_fwd<TF_B2, 1>(a, (int)c, 0); } break;
+    case TFK_CR_BWD: { const auto& a = *(const TfLevelArgs*)args;
+        if constexpr (TF_B2 <= 8) for (unsigned c = 0; c < gx; ++c) tfk_crs_bwd<TF_B2, 1>(a, (int)c, 0); } break;
     case TFK_TINY_FACTOR: { const auto& a = *(const TfTinyArgs*)args;
         for (int64_t t = 0; t < nthreads; ++t) tfk_tiny_factor_body(a, (int)t); } break;
     case TFK_TINY_SOLVE: { const auto& a = *(const TfTinyArgs*)args;

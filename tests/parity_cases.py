@@ -880,6 +880,42 @@ def check_two_resident_factorisations(backend):
         assert counts[1][2] == len(pattern), counts[1]
 
 
+def check_rescue_with_two_factorisations(backend):
+    """A constant-matrix model whose plan needs the rescue on longer chunks (linear dispersion,
+    u_t = -u_xxx, 4-node chunks) under the step-doubling pattern: both resident factorisations are
+    delegated to the one child solver, which holds a single factorisation -- a solve re-delegates
+    when the child's belongs to the other step size.  Same states as factorising in every step."""
+    import os
+    from triflow_amd.ensemble import Ensemble
+    compiler = hip_compiler if backend is None else partial(hip_compiler, backend=backend)
+    N = 203
+    x = np.linspace(0, N * 5e-3, N, endpoint=False)
+    U = (1.0 + 0.3 * np.cos(2 * np.pi * x / (N * 5e-3)))[None, :]
+    dt = 2e-3
+    pattern = ([10 * dt] + [dt] * 10) * 2
+    out, replans = [], []
+    for reuse in ("1", "0"):
+        m = Model("-dxxxU", "U", None, compiler=compiler)
+        os.environ["TRIFLOW_REUSE_FACTOR"] = reuse
+        try:
+            ens = Ensemble(m, x, dict(U=U), dict(periodic=True), True, scheme="Theta", nstate=2, m1=4, m_upper=2)
+        finally:
+            del os.environ["TRIFLOW_REUSE_FACTOR"]
+        assert ens.solver.constant_jacobian == (reuse == "1")
+        states = []
+        for h in pattern:
+            ens.step(h)
+            ens.sync()
+            states.append(ens.state().copy())
+        replans.append(ens.solver.counters()["replans"])
+        ens.close()
+        out.append(states)
+    assert replans[0] >= 1, replans                       # (the plan does need the rescue)
+    for k, (a, b) in enumerate(zip(*out)):
+        err = np.abs(a - b).max() / np.abs(b).max()
+        assert np.isfinite(a).all() and err <= 1e-10, (k, err)
+
+
 def check_ensemble_restart(backend):
     """Ensemble.restart(): back to the initial state on the device (bench.py uses it to keep long
     runs inside the time range where the film model stays smooth) -- the steps after a restart

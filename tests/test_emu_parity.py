@@ -39,6 +39,16 @@ def test_linear_solve(name, backend):
     pc.check_linear_solve(name, backend, 203, plans, tol=1e-7 if name == "wide4" else 1e-9)
 
 
+@pytest.mark.parametrize("name", ["M2_diff", "M3_film", "M5_stiff", "six"])
+def test_linear_solve_walk_levels(name, backend, monkeypatch):
+    """The reduced levels as chunk walks (tfk_bt_*: what block sizes above 8 run on the GPU, and
+    what TRIFLOW_REDUCED=walk selects); the other tests of this file run them as cyclic reduction
+    (tf_crs.h: one host "thread" per chunk)."""
+    monkeypatch.setenv("TRIFLOW_REDUCED", "walk")
+    plans = [dict(m1=4, m_upper=2), dict(m1=7, m_upper=3), dict(m1=32, m_upper=8)]
+    pc.check_linear_solve(name, backend, 203, plans, tol=1e-9)
+
+
 @pytest.mark.parametrize("case", [c for c in pc.STEP_CASES if c[0] in
                                   ("cfg1", "film_per", "stiff_clamp")],
                          ids=lambda c: c[0])
@@ -65,6 +75,10 @@ def test_bdf2(backend):
 
 def test_bdf2_interleaved(backend):
     pc.check_bdf2_interleaved(backend)
+
+
+def test_rescue_with_two_factorisations(backend):
+    pc.check_rescue_with_two_factorisations(backend)
 
 
 def test_two_resident_factorisations(backend):

@@ -419,6 +419,10 @@ def test_row_monitor():
     pc.check_row_monitor(HIP)
 
 
+def test_rescue_with_two_factorisations():
+    pc.check_rescue_with_two_factorisations(HIP)
+
+
 def test_two_resident_factorisations():
     pc.check_two_resident_factorisations(HIP)
 

@@ -13,6 +13,7 @@
 // partial pivoting inside the block, identical operation order per row), which
 // remain the version the host emulation runs.  HIP only.
 #pragma once
+#include "tf_crs.h"
 
 template <int BB> struct TfCoop {
     static constexpr int G = BB <= 2 ? 1 : (BB <= 8 ? 8 : (BB <= 16 ? 16 : 1));
@@ -426,24 +427,6 @@ template <int BB> struct TfCr {
     static constexpr int G = 8, NGRP = 8;
 };
 
-template <int BB>
-struct TfCrChunk {
-    int pg, e, p, len, start, mI, pe, gprev, pprev;
-    bool has_prev;
-    int64_t nbase;                                // first node record of system e
-    __device__ __forceinline__ TfCrChunk(const TfLayout& L, int chunk = (int)blockIdx.x) {
-        pg = chunk;
-        e = pg / L.P; p = pg - e * L.P;
-        len = tf_len(L, p); start = tf_start(L, p);
-        mI = len - 1; pe = len;
-        has_prev = L.periodic || p > 0;
-        gprev = start > 0 ? start - 1 : L.N - 1;
-        pprev = p > 0 ? p - 1 : L.P - 1;
-        nbase = (int64_t)e * L.N;
-    }
-    __device__ __forceinline__ int node(int pos) const { return start + pos - 1; }   // pos >= 1
-};
-
 // Gauss-Jordan inverse of a b x b block shared by the 8 lanes of a group: lane g
 // enters with row g of the block in S and leaves with row `myk` (returned) of the
 // inverse in INV.  Rows are never moved: the lane with the largest |S[.][k]| among
@@ -768,13 +751,13 @@ __device__ __forceinline__ void tfk_cr_bwd_run(const TfLevelArgs& a, const TfCrC
 template <int BB>
 __device__ __forceinline__ void tfk_cr_fwd_coop(const TfLevelArgs& a) {
     __shared__ TfCrSolveLds<BB> sh;
-    const TfCrChunk<BB> ch(a.L);
+    const TfCrChunk<BB> ch(a.L, (int)blockIdx.x);
     tfk_cr_fwd_chunk<BB>(a, ch, (int)threadIdx.x, sh, TfCrIo<BB>(a, ch));
 }
 template <int BB>
 __device__ __forceinline__ void tfk_cr_bwd_coop(const TfLevelArgs& a) {
     __shared__ TfCrSolveLds<BB> sh;
-    const TfCrChunk<BB> ch(a.L);
+    const TfCrChunk<BB> ch(a.L, (int)blockIdx.x);
     const TfCrIo<BB> io(a, ch);
     TfCrBwdRows<BB> rows;
     tfk_cr_bwd_load<BB>(a, ch, (int)threadIdx.x, io, rows, true);
@@ -901,343 +884,3 @@ __device__ __forceinline__ void tfk_top_factor_coop(const TfTopArgs& a) {
     }
 }
 
-// ===========================================================================
-// Cyclic reduction for scalar models (b = mp <= 2): one thread per node
-// ===========================================================================
-// Same algorithm, level format and stored quantities as tfk_cr_* above; the blocks are
-// 1 x 1 or 2 x 2, so a node is one thread's work and a chunk can be long: 256 nodes
-// per 256-thread workgroup, 8 rounds, levels shrink 256x (N = 1e6: 31250 -> 123 -> 1
-// chunks, where the chunk walks needed 6 levels of three kernels each).
-template <int BB> struct TfCrs {
-    static constexpr int MAXLEN = TF_CRS_MAXLEN, NPOS = MAXLEN + 1, NT = 256;
-};
-
-// small-block helpers on rows stored as [r * BB + c] in LDS / global memory
-template <int BB> __device__ __forceinline__ void tf_ld_blk(double (&m)[BB][BB], const double* p) {
-#pragma unroll
-    for (int r = 0; r < BB; ++r)
-#pragma unroll
-        for (int c = 0; c < BB; ++c) m[r][c] = p[r * BB + c];
-}
-template <int BB> __device__ __forceinline__ void tf_st_blk(double* p, const double (&m)[BB][BB]) {
-#pragma unroll
-    for (int r = 0; r < BB; ++r)
-#pragma unroll
-        for (int c = 0; c < BB; ++c) p[r * BB + c] = m[r][c];
-}
-
-template <int BB>
-__device__ __forceinline__ void tfk_crs_factor(const TfLevelArgs& a) {
-    typedef TfCrs<BB> C;
-    constexpr int NPOS = C::NPOS, NT = C::NT, B2 = BB * BB, REC = 4 * B2;
-    const TfLayout& L = a.L;
-    const TfCrChunk<BB> ch(L);
-    const int tid = threadIdx.x;
-    const int mI = ch.mI, pe = ch.pe, len = ch.len;
-    const bool with_rhs = a.cr_rhs != 0;
-    __shared__ double sL[NPOS * B2], sD[NPOS * B2], sU[NPOS * B2], sY[NPOS * BB], sZ[NPOS * BB];
-
-    // ---- load the chain (records of a chunk are contiguous)
-    {
-        const double* src = a.Ablk + (ch.nbase + ch.start) * REC;
-        const bool cut_first = !L.periodic && ch.start == 0, cut_last = !L.periodic && ch.start + len == L.N;
-        for (int i = tid; i < len * B2; i += NT) {
-            const int nd = i / B2, rc = i - nd * B2;
-            const double* rec = src + (int64_t)nd * REC;
-            sL[(nd + 1) * B2 + rc] = (cut_first && nd == 0) ? 0.0 : rec[rc];
-            sD[(nd + 1) * B2 + rc] = rec[B2 + rc] + rec[3 * B2 + rc];
-            sU[(nd + 1) * B2 + rc] = (cut_last && nd == len - 1) ? 0.0 : rec[2 * B2 + rc];
-        }
-        const double* prev = a.Ablk + (ch.nbase + ch.gprev) * REC;
-        for (int i = tid; i < B2; i += NT) {
-            sL[i] = 0.0; sD[i] = 0.0;
-            sU[i] = ch.has_prev ? prev[2 * B2 + i] : 0.0;
-        }
-        const double* ys = a.rhs + (ch.nbase + ch.start) * 2 * BB;
-        for (int i = tid; i < (len + 1) * BB; i += NT) {
-            const int pos = i / BB, r = i - pos * BB;
-            sY[i] = (with_rhs && pos > 0) ? ys[(pos - 1) * 2 * BB + r] + ys[(pos - 1) * 2 * BB + BB + r] : 0.0;
-        }
-    }
-    __syncthreads();
-
-    bool ok = true;
-    for (int s = 1; s <= mI; s <<= 1) {
-        // ---- phase A: every second remaining interior node goes
-        const int nA = (mI / s + 1) / 2;
-        for (int j = tid; j < nA; j += NT) {
-            const int k = s * (2 * j + 1);
-            double D[BB][BB], Di[BB][BB], Lk[BB][BB], Uk[BB][BB], E[BB][BB], F[BB][BB], z[BB], y[BB];
-            tf_ld_blk<BB>(D, sD + k * B2); tf_ld_blk<BB>(Lk, sL + k * B2); tf_ld_blk<BB>(Uk, sU + k * B2);
-#pragma unroll
-            for (int r = 0; r < BB; ++r) y[r] = sY[k * BB + r];
-            ok = tf_blk_inverse<BB>(D, Di) && ok;
-            tf_mm<BB>(E, Di, Lk); tf_mm<BB>(F, Di, Uk); tf_mv<BB>(z, Di, y);
-            double* rec = a.crf + (ch.nbase + ch.node(k)) * 5 * B2;
-            tf_st_blk<BB>(rec, Di); tf_st_blk<BB>(rec + B2, E); tf_st_blk<BB>(rec + 2 * B2, F);
-            tf_st_blk<BB>(sL + k * B2, E); tf_st_blk<BB>(sU + k * B2, F);
-#pragma unroll
-            for (int r = 0; r < BB; ++r) {
-                sZ[k * BB + r] = z[r];
-                if (with_rhs) a.zt[(ch.nbase + ch.node(k)) * BB + r] = z[r];
-            }
-        }
-        __syncthreads();
-        // ---- phase B: the neighbours take the update (tasks as in tfk_cr_factor_v3)
-        const int nB = mI / (2 * s);
-        for (int t = tid; t <= nB; t += NT) {
-            const bool ends = t == nB;
-            const int aa = 2 * s * (t + 1), nq = mI / s;
-            const int aL = ends ? pe : aa, aU = ends ? 0 : aa;
-            const bool vL = ends ? (nq & 1) != 0 : true;
-            const bool vR = ends ? true : aa + s <= mI;
-            const int kL = ends ? nq * s : aa - s, kR = ends ? s : aa + s;
-            if (vL) {
-                double Lr[BB][BB], Ek[BB][BB], Fk[BB][BB], Dn[BB][BB], nl[BB][BB], zk[BB], yv[BB];
-                tf_ld_blk<BB>(Lr, sL + aL * B2); tf_ld_blk<BB>(Ek, sL + kL * B2); tf_ld_blk<BB>(Fk, sU + kL * B2);
-                tf_ld_blk<BB>(Dn, sD + aL * B2);
-                tf_st_blk<BB>(a.crf + (ch.nbase + ch.node(kL)) * 5 * B2 + 4 * B2, Lr);
-                tf_blk_zero<BB>(nl);
-                tf_mm_sub<BB>(nl, Lr, Ek);            // -L E_kL
-                tf_mm_sub<BB>(Dn, Lr, Fk);            // D - L F_kL
-#pragma unroll
-                for (int r = 0; r < BB; ++r) { zk[r] = sZ[kL * BB + r]; yv[r] = sY[aL * BB + r]; }
-                tf_mv_sub<BB>(yv, Lr, zk);
-                tf_st_blk<BB>(sL + aL * B2, nl); tf_st_blk<BB>(sD + aL * B2, Dn);
-#pragma unroll
-                for (int r = 0; r < BB; ++r) sY[aL * BB + r] = yv[r];
-            }
-            if (vR) {
-                double Ur[BB][BB], Ek[BB][BB], Fk[BB][BB], Dn[BB][BB], nu[BB][BB], zk[BB], yv[BB];
-                tf_ld_blk<BB>(Ur, sU + aU * B2); tf_ld_blk<BB>(Ek, sL + kR * B2); tf_ld_blk<BB>(Fk, sU + kR * B2);
-                tf_ld_blk<BB>(Dn, sD + aU * B2);
-                tf_st_blk<BB>(a.crf + (ch.nbase + ch.node(kR)) * 5 * B2 + 3 * B2, Ur);
-                tf_blk_zero<BB>(nu);
-                tf_mm_sub<BB>(nu, Ur, Fk);            // -U F_kR
-                tf_mm_sub<BB>(Dn, Ur, Ek);            // D - U E_kR
-#pragma unroll
-                for (int r = 0; r < BB; ++r) { zk[r] = sZ[kR * BB + r]; yv[r] = sY[aU * BB + r]; }
-                tf_mv_sub<BB>(yv, Ur, zk);
-                tf_st_blk<BB>(sU + aU * B2, nu); tf_st_blk<BB>(sD + aU * B2, Dn);
-#pragma unroll
-                for (int r = 0; r < BB; ++r) sY[aU * BB + r] = yv[r];
-            }
-        }
-        __syncthreads();
-    }
-
-    // ---- this chunk's share of the next level's rows
-    if (tid < 2) {
-        const int nn = tid == 0 ? ch.p : ch.pprev;
-        double* rec = a.Anext + ((int64_t)ch.e * a.Lnext.N + nn) * REC;
-        double* rr = a.rhsnext + ((int64_t)ch.e * a.Lnext.N + nn) * 2 * BB;
-        for (int i = 0; i < B2; ++i) {
-            if (tid == 0) { rec[i] = sL[pe * B2 + i]; rec[B2 + i] = sD[pe * B2 + i]; }
-            else { rec[2 * B2 + i] = sU[i]; rec[3 * B2 + i] = sD[i]; }
-        }
-        if (with_rhs)
-            for (int r = 0; r < BB; ++r) { if (tid == 0) rr[r] = sY[pe * BB + r]; else rr[BB + r] = sY[r]; }
-    }
-    if (a.fold_top) {
-        // one chunk per system: invert what is left, solve for the first rhs, back-substitute
-        __syncthreads();
-        if (tid == 0) {
-            double S[BB][BB], Si[BB][BB];
-#pragma unroll
-            for (int r = 0; r < BB; ++r)
-#pragma unroll
-                for (int c = 0; c < BB; ++c) {
-                    const int i = r * BB + c;
-                    S[r][c] = sL[pe * B2 + i] + sD[pe * B2 + i] + sU[i] + sD[i];
-                }
-            ok = tf_blk_inverse<BB>(S, Si) && ok;
-            const int nsys = L.Ptot;
-#pragma unroll
-            for (int r = 0; r < BB; ++r)
-#pragma unroll
-                for (int c = 0; c < BB; ++c) a.topAinv[(int64_t)(r * BB + c) * nsys + ch.e] = Si[r][c];
-            if (with_rhs) {
-                double yt[BB], x[BB];
-#pragma unroll
-                for (int r = 0; r < BB; ++r) yt[r] = sY[pe * BB + r] + sY[r];
-                tf_mv<BB>(x, Si, yt);
-#pragma unroll
-                for (int r = 0; r < BB; ++r) {
-                    a.topx[(int64_t)ch.e * BB + r] = x[r];
-                    a.x[(ch.nbase + ch.node(pe)) * BB + r] = x[r];
-                    sY[pe * BB + r] = x[r];
-                    sY[r] = ch.has_prev ? x[r] : 0.0;
-                }
-            }
-        }
-        __syncthreads();
-        if (with_rhs) {
-            int s = 1;
-            while (2 * s <= mI) s <<= 1;
-            for (; s >= 1; s >>= 1) {
-                const int nA = (mI / s + 1) / 2;
-                for (int j = tid; j < nA; j += NT) {
-                    const int k = s * (2 * j + 1);
-                    const int kl = k - s, kr = k + s <= mI ? k + s : pe;
-                    double E[BB][BB], F[BB][BB], xl[BB], xr[BB], xk[BB];
-                    tf_ld_blk<BB>(E, sL + k * B2); tf_ld_blk<BB>(F, sU + k * B2);
-#pragma unroll
-                    for (int r = 0; r < BB; ++r) { xk[r] = sZ[k * BB + r]; xl[r] = sY[kl * BB + r]; xr[r] = sY[kr * BB + r]; }
-                    tf_mv_sub<BB>(xk, E, xl); tf_mv_sub<BB>(xk, F, xr);
-#pragma unroll
-                    for (int r = 0; r < BB; ++r) { sY[k * BB + r] = xk[r]; a.x[(ch.nbase + ch.node(k)) * BB + r] = xk[r]; }
-                }
-                __syncthreads();
-            }
-        }
-    }
-    if (!ok) *a.status = 1;
-}
-
-template <int BB>
-__device__ __forceinline__ void tfk_crs_fwd(const TfLevelArgs& a) {
-    typedef TfCrs<BB> C;
-    constexpr int NPOS = C::NPOS, NT = C::NT, B2 = BB * BB;
-    const TfLayout& L = a.L;
-    const TfCrChunk<BB> ch(L);
-    const int tid = threadIdx.x;
-    const int mI = ch.mI, pe = ch.pe, len = ch.len;
-    __shared__ double sF[NPOS * 5 * B2];             // stored reduction of the chunk's nodes
-    __shared__ double sY[NPOS * BB], sZ[NPOS * BB];
-    {
-        const double* src = a.crf + (ch.nbase + ch.start) * 5 * B2;
-        for (int i = tid; i < len * 5 * B2; i += NT) sF[5 * B2 + i] = src[i];
-        const double* ys = a.rhs + (ch.nbase + ch.start) * 2 * BB;
-        for (int i = tid; i < (len + 1) * BB; i += NT) {
-            const int pos = i / BB, r = i - pos * BB;
-            sY[i] = pos > 0 ? ys[(pos - 1) * 2 * BB + r] + ys[(pos - 1) * 2 * BB + BB + r] : 0.0;
-        }
-    }
-    __syncthreads();
-    for (int s = 1; s <= mI; s <<= 1) {
-        const int nA = (mI / s + 1) / 2;
-        for (int j = tid; j < nA; j += NT) {
-            const int k = s * (2 * j + 1);
-            double Di[BB][BB], y[BB], z[BB];
-            tf_ld_blk<BB>(Di, sF + k * 5 * B2);
-#pragma unroll
-            for (int r = 0; r < BB; ++r) y[r] = sY[k * BB + r];
-            tf_mv<BB>(z, Di, y);
-#pragma unroll
-            for (int r = 0; r < BB; ++r) { sZ[k * BB + r] = z[r]; a.zt[(ch.nbase + ch.node(k)) * BB + r] = z[r]; }
-        }
-        __syncthreads();
-        const int nB = mI / (2 * s);
-        for (int t = tid; t <= nB; t += NT) {
-            const bool ends = t == nB;
-            const int aa = 2 * s * (t + 1), nq = mI / s;
-            const int aL = ends ? pe : aa, aU = ends ? 0 : aa;
-            const bool vL = ends ? (nq & 1) != 0 : true;
-            const bool vR = ends ? true : aa + s <= mI;
-            const int kL = ends ? nq * s : aa - s, kR = ends ? s : aa + s;
-            if (vL) {
-                double Lb[BB][BB], zk[BB], yv[BB];
-                tf_ld_blk<BB>(Lb, sF + kL * 5 * B2 + 4 * B2);
-#pragma unroll
-                for (int r = 0; r < BB; ++r) { zk[r] = sZ[kL * BB + r]; yv[r] = sY[aL * BB + r]; }
-                tf_mv_sub<BB>(yv, Lb, zk);
-#pragma unroll
-                for (int r = 0; r < BB; ++r) sY[aL * BB + r] = yv[r];
-            }
-            if (vR) {
-                double Ua[BB][BB], zk[BB], yv[BB];
-                tf_ld_blk<BB>(Ua, sF + kR * 5 * B2 + 3 * B2);
-#pragma unroll
-                for (int r = 0; r < BB; ++r) { zk[r] = sZ[kR * BB + r]; yv[r] = sY[aU * BB + r]; }
-                tf_mv_sub<BB>(yv, Ua, zk);
-#pragma unroll
-                for (int r = 0; r < BB; ++r) sY[aU * BB + r] = yv[r];
-            }
-        }
-        __syncthreads();
-    }
-    if (a.fold_top) {
-        if (tid == 0) {
-            const int nsys = L.Ptot;
-            double Si[BB][BB], yt[BB], x[BB];
-#pragma unroll
-            for (int r = 0; r < BB; ++r) {
-                yt[r] = sY[pe * BB + r] + sY[r];
-#pragma unroll
-                for (int c = 0; c < BB; ++c) Si[r][c] = a.topAinv[(int64_t)(r * BB + c) * nsys + ch.e];
-            }
-            tf_mv<BB>(x, Si, yt);
-#pragma unroll
-            for (int r = 0; r < BB; ++r) {
-                a.topx[(int64_t)ch.e * BB + r] = x[r];
-                a.x[(ch.nbase + ch.node(pe)) * BB + r] = x[r];
-                sY[pe * BB + r] = x[r];
-                sY[r] = ch.has_prev ? x[r] : 0.0;
-            }
-        }
-        __syncthreads();
-        int s = 1;
-        while (2 * s <= mI) s <<= 1;
-        for (; s >= 1; s >>= 1) {
-            const int nA = (mI / s + 1) / 2;
-            for (int j = tid; j < nA; j += NT) {
-                const int k = s * (2 * j + 1);
-                const int kl = k - s, kr = k + s <= mI ? k + s : pe;
-                double E[BB][BB], F[BB][BB], xl[BB], xr[BB], xk[BB];
-                tf_ld_blk<BB>(E, sF + k * 5 * B2 + B2); tf_ld_blk<BB>(F, sF + k * 5 * B2 + 2 * B2);
-#pragma unroll
-                for (int r = 0; r < BB; ++r) { xk[r] = sZ[k * BB + r]; xl[r] = sY[kl * BB + r]; xr[r] = sY[kr * BB + r]; }
-                tf_mv_sub<BB>(xk, E, xl); tf_mv_sub<BB>(xk, F, xr);
-#pragma unroll
-                for (int r = 0; r < BB; ++r) { sY[k * BB + r] = xk[r]; a.x[(ch.nbase + ch.node(k)) * BB + r] = xk[r]; }
-            }
-            __syncthreads();
-        }
-    } else if (tid < 2) {
-        const int nn = tid == 0 ? ch.p : ch.pprev;
-        double* rr = a.rhsnext + ((int64_t)ch.e * a.Lnext.N + nn) * 2 * BB;
-        for (int r = 0; r < BB; ++r) { if (tid == 0) rr[r] = sY[pe * BB + r]; else rr[BB + r] = sY[r]; }
-    }
-}
-
-template <int BB>
-__device__ __forceinline__ void tfk_crs_bwd(const TfLevelArgs& a) {
-    typedef TfCrs<BB> C;
-    constexpr int NPOS = C::NPOS, NT = C::NT, B2 = BB * BB;
-    const TfLayout& L = a.L;
-    const TfCrChunk<BB> ch(L);
-    const int tid = threadIdx.x;
-    const int mI = ch.mI, pe = ch.pe, len = ch.len;
-    __shared__ double sF[NPOS * 5 * B2];
-    __shared__ double sX[NPOS * BB], sZ[NPOS * BB];
-    {
-        const double* src = a.crf + (ch.nbase + ch.start) * 5 * B2;
-        for (int i = tid; i < len * 5 * B2; i += NT) sF[5 * B2 + i] = src[i];
-        const double* zs = a.zt + (ch.nbase + ch.start) * BB;
-        for (int i = tid; i < len * BB; i += NT) sZ[BB + i] = zs[i];
-    }
-    if (tid < BB) {
-        const double xs = a.xnext[((int64_t)ch.e * a.Lnext.N + ch.p) * BB + tid];
-        sX[pe * BB + tid] = xs;
-        a.x[(ch.nbase + ch.node(pe)) * BB + tid] = xs;
-        sX[tid] = ch.has_prev ? a.xnext[((int64_t)ch.e * a.Lnext.N + ch.pprev) * BB + tid] : 0.0;
-    }
-    __syncthreads();
-    int s = 1;
-    while (2 * s <= mI) s <<= 1;
-    for (; s >= 1; s >>= 1) {
-        const int nA = (mI / s + 1) / 2;
-        for (int j = tid; j < nA; j += NT) {
-            const int k = s * (2 * j + 1);
-            const int kl = k - s, kr = k + s <= mI ? k + s : pe;
-            double E[BB][BB], F[BB][BB], xl[BB], xr[BB], xk[BB];
-            tf_ld_blk<BB>(E, sF + k * 5 * B2 + B2); tf_ld_blk<BB>(F, sF + k * 5 * B2 + 2 * B2);
-#pragma unroll
-            for (int r = 0; r < BB; ++r) { xk[r] = sZ[k * BB + r]; xl[r] = sX[kl * BB + r]; xr[r] = sX[kr * BB + r]; }
-            tf_mv_sub<BB>(xk, E, xl); tf_mv_sub<BB>(xk, F, xr);
-#pragma unroll
-            for (int r = 0; r < BB; ++r) { sX[k * BB + r] = xk[r]; a.x[(ch.nbase + ch.node(k)) * BB + r] = xk[r]; }
-        }
-        __syncthreads();
-    }
-}

@@ -260,7 +260,7 @@ __device__ __forceinline__ void tfk_cr_factor_v3(const TfLevelArgs& a) {
     constexpr int NO = 2 * BB + 1, NOJ = (NO + 7) / 8;      // outputs of one side of a phase-B task
     static_assert(oL == 0 && oD == BB && oU == 2 * BB && oY == 3 * BB, "LDS row order = augmented order");
     const TfLayout& L = a.L;
-    const TfCrChunk<BB> ch(L);
+    const TfCrChunk<BB> ch(L, (int)blockIdx.x);
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane & 7, h = lane >> 3;
     const int gq = g < BB ? g : 0;
     const int mI = ch.mI, pe = ch.pe, len = ch.len;

@@ -292,15 +292,15 @@ __global__ void __launch_bounds__(64) tfk_tiny_solve(TfTinyArgs a) { tfk_tiny_so
 #endif
 __global__ void __attribute__((amdgpu_waves_per_eu(TF_CR_FACTOR_WAVES))) __launch_bounds__(TF_CR_FACTOR_BLOCK)
 tfk_cr_factor(TfLevelArgs a) {
-    if constexpr (TF_B2 <= 2) tfk_crs_factor<TF_B2>(a);
+    if constexpr (TF_B2 <= 2) tfk_crs_factor<TF_B2, 256>(a, (int)blockIdx.x, (int)threadIdx.x);
     else if constexpr (TF_B2 <= 8) tfk_cr_factor_v3<TF_B2>(a);
 }
 __global__ void __launch_bounds__(TF_CR_BLOCK) tfk_cr_fwd(TfLevelArgs a) {
-    if constexpr (TF_B2 <= 2) tfk_crs_fwd<TF_B2>(a);
+    if constexpr (TF_B2 <= 2) tfk_crs_fwd<TF_B2, 256>(a, (int)blockIdx.x, (int)threadIdx.x);
     else if constexpr (TF_B2 <= 8) tfk_cr_fwd_coop<TF_B2>(a);
 }
 __global__ void __launch_bounds__(TF_CR_BLOCK) tfk_cr_bwd(TfLevelArgs a) {
-    if constexpr (TF_B2 <= 2) tfk_crs_bwd<TF_B2>(a);
+    if constexpr (TF_B2 <= 2) tfk_crs_bwd<TF_B2, 256>(a, (int)blockIdx.x, (int)threadIdx.x);
     else if constexpr (TF_B2 <= 8) tfk_cr_bwd_coop<TF_B2>(a);
 }
 // the last two levels of a solve: one workgroup per system (3 <= b <= 8; the host only launches it there)

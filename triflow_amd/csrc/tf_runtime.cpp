@@ -558,8 +558,7 @@ struct tf_solver {
     bool l1_fuse_asm = true;
     bool fuse_asm_ok() const {
         const int b = spec.mp * spec.nvar;
-        return l1_fuse_asm && tfb::is_device_build() && levels.size() > 1 && levels[1]->cr &&
-               (2 * b * b + 1) * 64 * 8 <= 40 * 1024;
+        return l1_fuse_asm && levels.size() > 1 && levels[1]->cr && (2 * b * b + 1) * 64 * 8 <= 40 * 1024;
     }
     // N < 2*mp + 1: dense factorisation, one thread per system (tfk_tiny_*)
     bool tiny = false;
@@ -763,7 +762,7 @@ struct tf_solver {
     bool cr_tail = true;           // (TRIFLOW_CR_TAIL=0: A/B runs)
     bool tail_ok() const {
         const size_t n = levels.size();
-        return cr_tail && n >= 3 && top.B >= 3 && top.B <= 6 && levels[n - 1]->cr && levels[n - 2]->cr &&
+        return cr_tail && tfb::is_device_build() && n >= 3 && top.B >= 3 && top.B <= 6 && levels[n - 1]->cr && levels[n - 2]->cr &&
                levels[n - 1]->L.P == 1 && levels[n - 2]->L.P <= 8;      // TF_CR_TAIL_MAXB, TF_CR_TAIL_WAVES
     }
     void solve_once(const double* rhs1, double* x1) {
@@ -849,6 +848,11 @@ struct tf_solver {
         perm(1 /*OUT_SOA*/, src_planes, staging.p, ncomp);
         dst->perm(0 /*IN_SOA*/, staging.p, dst_planes, ncomp);
     }
+    // what the child's factorisation in memory belongs to (the child holds one; both sets of factor
+    // buffers of a constant-matrix solver may be delegated)
+    double fb_c = 0.0;
+    uint64_t fb_ver = 0;
+    bool fb_valid = false;
     void delegate_factor(double c) {
         tf_solver* fb = ensure_fallback();
         fb->mode = mode;
@@ -860,10 +864,12 @@ struct tf_solver {
         fb->have_jac = true;
         fb->have_factor = false;
         fb->factor(c);
+        fb_c = c; fb_ver = par_ver; fb_valid = true;
         delegated = true;
         fact_needs_refine = true;                    // (reported as "refined": the plan in use is not the one asked for)
     }
     void delegate_solve(const double* rhs1, double* x1) {
+        if (!(fb_valid && fb_c == factor_c && fb_ver == par_ver)) delegate_factor(factor_c);
         tf_solver* fb = fallback;
         fb->mode = mode;
         transfer_to(fb, rhs1, fb->Wrhs.p, spec.nvar);
@@ -1605,7 +1611,9 @@ int tf_step_doubling(tf_solver* s, int32_t src, int32_t dst, int32_t tmp, int32_
         from = to;
     }
     std::vector<double> norms((size_t)s->nsys * s->spec.nvar);
-    diff_norm(s, coarse, dst, ord, norms.data(), true);            // the one synchronisation (norms + status)
+    // the one synchronisation: the norms.  (Device-side failures surface at the next synchronising
+    // call, as for a trial driven step by step: no second wait, no extra copies here.)
+    diff_norm(s, coarse, dst, ord, norms.data());
     for (int e = 0; e < s->nsys; ++e) {
         double worst = 0.0;
         for (int v = 0; v < s->spec.nvar; ++v) {
