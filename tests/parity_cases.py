@@ -527,7 +527,8 @@ def check_fused_step_doubling(backend):
             _capi.DeviceSolver.step_theta = counted("step_theta", "single")
             _capi.DeviceSolver.step_row = counted("step_row", "single")
             _capi.DeviceSolver.step_doubling = counted("step_doubling", "doubling")
-            saved = schemes._fused_trial
+            saved, saved_flag = schemes._fused_trial, schemes.FUSED_TRIALS
+            schemes.FUSED_TRIALS = True               # (off by default: the fused call is not faster)
             if not fused:
                 schemes._fused_trial = lambda *a, **k: None
             try:
@@ -537,7 +538,7 @@ def check_fused_step_doubling(backend):
                     t, f = scheme(t, f, dt, pars, **kw)
                 out.append((t, f.uflat.copy()))
             finally:
-                schemes._fused_trial = saved
+                schemes._fused_trial, schemes.FUSED_TRIALS = saved, saved_flag
                 for k, v in orig.items():
                     setattr(_capi.DeviceSolver, k, v)
             calls.append(counts)

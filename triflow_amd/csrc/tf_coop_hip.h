@@ -784,7 +784,7 @@ __device__ __forceinline__ void tfk_cr_tail_coop(const TfTailArgs& t) {
     __shared__ double sCrfTop[NW * 5 * B2];          // level T+1: stored reduction of its one chunk (<= NW nodes)
     __shared__ double sRhsTop[NW * 2 * BB];          // ... its right-hand side records (two parts per node)
     __shared__ double sXTop[NW * BB];                // ... its solution
-    const int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63, e = (int)blockIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63, e = (int)blockIdx.x;
     const TfLevelArgs& la = t.lv[0];
     const TfLevelArgs& lb = t.lv[1];
     const int P = la.L.P;                            // <= NW (host)

@@ -249,6 +249,9 @@ __device__ __forceinline__ int tf_gj_node(double (&val)[(NC + 7) / 8], int g, in
     return myk;
 }
 
+#ifndef TF_CR_SCALAR_W
+#define TF_CR_SCALAR_W 1           // 0: the wavefront index as every lane computes it (A/B runs)
+#endif
 template <int BB>
 __device__ __forceinline__ void tfk_cr_factor_v3(const TfLevelArgs& a) {
     typedef TfCr2<BB> C;
@@ -261,7 +264,11 @@ __device__ __forceinline__ void tfk_cr_factor_v3(const TfLevelArgs& a) {
     static_assert(oL == 0 && oD == BB && oU == 2 * BB && oY == 3 * BB, "LDS row order = augmented order");
     const TfLayout& L = a.L;
     const TfCrChunk<BB> ch(L, (int)blockIdx.x);
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane & 7, h = lane >> 3;
+    // (the wavefront index as a scalar: the task loops of the rounds, the chain positions a task
+    // touches and the record addresses are the same for every lane -- scalar registers and scalar
+    // branches instead of per-lane arithmetic and exec-mask loops)
+    const int tid = threadIdx.x, w = TF_CR_SCALAR_W ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6,
+              lane = tid & 63, g = lane & 7, h = lane >> 3;
     const int gq = g < BB ? g : 0;
     const int mI = ch.mI, pe = ch.pe, len = ch.len;
     const bool with_rhs = a.cr_rhs != 0;

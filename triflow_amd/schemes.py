@@ -23,6 +23,7 @@ and arbitrary Python hooks are served.
 """
 
 import logging
+import os
 import weakref
 from functools import wraps
 
@@ -86,6 +87,14 @@ def _difference_norms(a, b, ord):
             for key in b.dependent_variables]
 
 
+#: A whole trial of the step-doubling controller as one library call (``tf_step_doubling``).  Off by
+#: default since round 3: the launches are asynchronous either way and the GPU is the bottleneck, so
+#: the fused call has never been faster than the loop below (config 2, N = 1e6: 0.670 against 0.657 ms
+#: per trial; config 3: equal -- profiles/r03_step_doubling_trial.txt).  ``TRIFLOW_FUSED_TRIAL=1``
+#: (or setting this flag) switches it on; results are bit-identical (``check_fused_step_doubling``).
+FUSED_TRIALS = os.environ.get("TRIFLOW_FUSED_TRIAL", "0") == "1"
+
+
 def _fused_trial(scheme, t, fields, dt_, m, pars, hook, ord):
     """One trial of the step-doubling controller as ONE call into the device library
     (``tf_step_doubling``: the coarse step, the ten fine steps and the norm of their
@@ -124,7 +133,7 @@ def time_stepping(scheme, tol=1e-1, ord=2, m=10, reject_factor=2):
     def one_step(t, fields, dt, pars, hook):
         dt_ = dt
         while True:
-            fused = _fused_trial(scheme, t, fields, dt_, m, pars, hook, ord)
+            fused = _fused_trial(scheme, t, fields, dt_, m, pars, hook, ord) if FUSED_TRIALS else None
             if fused is not None:
                 fields, err = fused
                 for _ in range(10):
