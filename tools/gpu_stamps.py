@@ -33,6 +33,12 @@ for l in range(1, len(s.describe()["chunks"])):
     print("level %d: %d cycles = %.2f us (clock %.2f GHz)  load %d | rounds (A, B): %s | share %d | fold/end %d"
           % (l + 1, total, real, total / real / 1e3 if real else 0, d[0],
              " ".join("(%d, %d)" % (d[1 + 2 * i], d[2 + 2 * i]) for i in range((len(d) - 3) // 2)), d[-2], d[-1]))
+    if r[44]:
+        print("         round 2, wavefront 0: phase A starts %d cycles after the barrier; block inversion (load + eliminate) %d, stores %d"
+              % (r[44] - marks[3], r[45] - r[44], r[46] - r[45]))
+    if r[47]:
+        print("         round 2, wavefront 0: phase B prologue (old values, stored blocks) %d cycles after the barrier, products %d, then stores + barrier %d"
+              % (r[47] - marks[4], r[48] - r[47], marks[5] - r[48]))
     if r[50]:
         print("         tail kernel (this level + the last one): " + " ".join(str(int(v)) for v in np.diff(r[50:57])) + " cycles (requests, forward, park, last level, barrier, backward)")
     if r[41]:

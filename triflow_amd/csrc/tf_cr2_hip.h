@@ -326,6 +326,14 @@ __device__ __forceinline__ void tfk_cr_factor_v3(const TfLevelArgs& a) {
     __syncthreads();
 
     bool ok = true;
+    // offset of augmented column h + 8j inside a node's stored record [D^-1, E, F, ..] (without the
+    // row), -1 = not stored (the D slot, the y slot -- z goes to a.zt -- and the padding)
+    int goff[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int c = h + 8 * j;
+        goff[j] = c < BB ? 1 * B2 + c : ((c >= oU && c < oY) ? 2 * B2 + c - oU : ((c > oY && c < NC) ? c - RW : -1));
+    }
     TF_STAMP(a, 1);
     int stamp_i = 2;
     for (int r = 0; (1 << r) <= mI; ++r) {
@@ -339,25 +347,27 @@ __device__ __forceinline__ void tfk_cr_factor_v3(const TfLevelArgs& a) {
             const unsigned code0 = code;
             bool searched = false;
             const double* rk0 = row(k, 0);
+            if (r == 1) TF_STAMP(a, 44);
             const int myk = tf_gj_node<BB, NC, oD>(val, g, h, code, ok, [&](int rr, int c) {
                 return rr < 0 ? 0.0 : (c < RW ? rk0[rr * RS + c] : ((c < NC && c - RW == rr) ? 1.0 : 0.0)); }, &searched);
+            if (r == 1) TF_STAMP(a, 45);
             if (code != code0 && lane == 0) perm[k - 1] = code;
             TF_COUNT(a, 41);
             if (searched) TF_COUNT(a, 40);
-            // my row is row myk of [E | . | F | z | D^-1]
+            // my row is row myk of [E | . | F | z | D^-1]: where each of my entries goes in the node's
+            // stored record was worked out once (goff), so that the stores are four predicated
+            // instructions and not a chain of branches per entry
             if (g < BB) {
                 double* dst = row(k, myk);
                 double* rec = a.crf + (ch.nbase + ch.node(k)) * 5 * B2 + myk * BB;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const int c = h + 8 * j;
-                    if (c < RW) dst[c] = val[j];                     // (the D slot is dead from here on)
-                    if (c < BB) rec[1 * B2 + c] = val[j];
-                    else if (c >= oU && c < oY) rec[2 * B2 + c - oU] = val[j];
-                    else if (c == oY) { if (with_rhs) a.zt[(ch.nbase + ch.node(k)) * BB + myk] = val[j]; }
-                    else if (c > oY && c < NC) rec[c - RW] = val[j];
+                    if (h + 8 * j < RW) dst[h + 8 * j] = val[j];     // (the D slot is dead from here on)
+                    if (goff[j] >= 0) rec[goff[j]] = val[j];
                 }
+                if (with_rhs && h == (oY & 7)) a.zt[(ch.nbase + ch.node(k)) * BB + myk] = val[oY >> 3];
             }
+            if (r == 1) TF_STAMP(a, 46);
         }
         __syncthreads();
         TF_STAMP(a, stamp_i); ++stamp_i;
@@ -391,6 +401,7 @@ __device__ __forceinline__ void tfk_cr_factor_v3(const TfLevelArgs& a) {
                 if (vL) a.crf[(ch.nbase + ch.node(kL)) * 5 * B2 + 4 * B2 + g * BB + h] = raL[oL + h];
                 if (vR) a.crf[(ch.nbase + ch.node(kR)) * 5 * B2 + 3 * B2 + g * BB + h] = raU[oU + h];
             }
+            if (r == 1) TF_STAMP(a, 47);
             const int s0 = isy ? oY : oL + hc, s1 = isy ? oY : oU + hc;      // source columns of j = 0, 1
             double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, y0 = 0.0, y1 = 0.0;
             // (the row's coupling entries are read where they are used, not kept: registers)
@@ -405,6 +416,7 @@ __device__ __forceinline__ void tfk_cr_factor_v3(const TfLevelArgs& a) {
                 a3 = tf_fma(um, eR[oL + hc], a3);
                 if (YSEP) { y0 = tf_fma(lm, eL[oY], y0); y1 = tf_fma(um, eR[oY], y1); }
             }
+            if (r == 1) TF_STAMP(a, 48);
             if (g < BB) {
                 if (h < BB) {
                     if (vL) raL[oL + h] = a0;
