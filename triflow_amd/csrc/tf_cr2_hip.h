@@ -326,14 +326,6 @@ __device__ __forceinline__ void tfk_cr_factor_v3(const TfLevelArgs& a) {
     __syncthreads();
 
     bool ok = true;
-    // offset of augmented column h + 8j inside a node's stored record [D^-1, E, F, ..] (without the
-    // row), -1 = not stored (the D slot, the y slot -- z goes to a.zt -- and the padding)
-    int goff[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int c = h + 8 * j;
-        goff[j] = c < BB ? 1 * B2 + c : ((c >= oU && c < oY) ? 2 * B2 + c - oU : ((c > oY && c < NC) ? c - RW : -1));
-    }
     TF_STAMP(a, 1);
     int stamp_i = 2;
     for (int r = 0; (1 << r) <= mI; ++r) {
@@ -354,18 +346,21 @@ __device__ __forceinline__ void tfk_cr_factor_v3(const TfLevelArgs& a) {
             if (code != code0 && lane == 0) perm[k - 1] = code;
             TF_COUNT(a, 41);
             if (searched) TF_COUNT(a, 40);
-            // my row is row myk of [E | . | F | z | D^-1]: where each of my entries goes in the node's
-            // stored record was worked out once (goff), so that the stores are four predicated
-            // instructions and not a chain of branches per entry
+            // my row is row myk of [E | . | F | z | D^-1]
+            // (the entries' places in the stored record worked out once per lane, as predicated stores,
+            // measured no faster and cost five registers: profiles/r03_ab_runs.txt)
             if (g < BB) {
                 double* dst = row(k, myk);
                 double* rec = a.crf + (ch.nbase + ch.node(k)) * 5 * B2 + myk * BB;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    if (h + 8 * j < RW) dst[h + 8 * j] = val[j];     // (the D slot is dead from here on)
-                    if (goff[j] >= 0) rec[goff[j]] = val[j];
+                    const int c = h + 8 * j;
+                    if (c < RW) dst[c] = val[j];                     // (the D slot is dead from here on)
+                    if (c < BB) rec[1 * B2 + c] = val[j];
+                    else if (c >= oU && c < oY) rec[2 * B2 + c - oU] = val[j];
+                    else if (c == oY) { if (with_rhs) a.zt[(ch.nbase + ch.node(k)) * BB + myk] = val[j]; }
+                    else if (c > oY && c < NC) rec[c - RW] = val[j];
                 }
-                if (with_rhs && h == (oY & 7)) a.zt[(ch.nbase + ch.node(k)) * BB + myk] = val[oY >> 3];
             }
             if (r == 1) TF_STAMP(a, 46);
         }
