@@ -553,6 +553,30 @@ def test_bench_process_group_one_rank():
     assert len(c4["per_rank"]) == 1
 
 
+def test_bench_two_ranks_rehearsal():
+    """The N > 1 path of bench.py with two real ranks on this one GPU (Gloo process group, both on
+    device 0: RCCL refuses ranks that share a card): member sharding by rank, the broadcast of the
+    table, barriers, the max over ranks per block, the self-description of the line, and the
+    config-4 block (8 members per rank) -- launched the way the driver launches it."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TRIFLOW_BENCH_BACKEND="gloo", TRIFLOW_BENCH_CONFIG4="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29641", os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--nodes", "100000", "--steps", "5", "--warmup", "2", "--repeats", "3",
+                          "--no-cpu-baseline", "--plain"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    line = json.loads([ln for ln in res.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["members_per_rank"] == [1, 1]
+    assert line["backend"].startswith("gloo") and len(line["steps_per_s_per_rank"]) == 2
+    assert line["value"] > 0 and line["scaling"] == "weak"
+    # value = both members over the slowest rank's block time: not above the sum of the ranks' own rates
+    assert line["value"] <= 1.001 * sum(line["steps_per_s_per_rank"])
+    c4 = line["config4"]
+    assert c4["members"] == 16 and c4["members_per_rank"] == [8, 8] and len(c4["per_rank"]) == 2
+
+
 def test_bench_line_carries_its_parity():
     """bench.py holds the device state of its own run to the oracle state of its cpu_baseline leg
     (same inputs, same steps) and fails above the bound: here at a size the oracle does in a second."""

@@ -632,7 +632,10 @@ struct tf_solver {
         const int mI_max = a.L.M - spec.mp;
         a.ylds_rows = std::max(half(mI_max), a.L.rem > 0 ? half(mI_max - 1) : 0);
         const size_t lds = (size_t)2 * a.ylds_rows * spec.nvar * 64 * sizeof(double);
-        return lds <= 64u * 1024u ? (unsigned)lds : 0u;
+        // (up to half of a CU's 160 KB: two workgroups = four wavefronts, one per SIMD; the stiff model's
+        // 80 KB just fit -- config 5 687 -> 698 steps/s, profiles/r03_ab_runs.txt r3n)
+        static const size_t lds_max = getenv("TRIFLOW_L1_LDS_MAX") ? (size_t)atoll(getenv("TRIFLOW_L1_LDS_MAX")) : 80u * 1024u;
+        return lds <= lds_max ? (unsigned)lds : 0u;
     }
     TfLevelArgs level_args(size_t l, const double* rhs1, double* x1) {
         Level& lv = *levels[l];
