@@ -205,6 +205,9 @@ int tf_monitor_error(tf_solver*, double* worst);
  * checks that waited for the device, and factorisations that were redone on longer chunks because
  * the first attempt lost accuracy */
 int tf_solver_counters(tf_solver*, int64_t* factorisations, int64_t* checks, int64_t* replans);
+/* the workgroup size a kernel of the model's code object was built for (tfk_l1_factor*: 128 when
+ * the factorisation walks are split over two wavefronts, tf_args.h TF_L1_SPLIT_MODEL) */
+int tf_solver_kernel_block(tf_solver*, int32_t kernel, int32_t* block);
 int tf_sync(tf_solver*);            /* waits for the stream, reports device-side failures */
 
 /* ---- measurement: kernel begin/end timestamps (HIP events attached to the

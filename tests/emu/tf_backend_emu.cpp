@@ -68,6 +68,7 @@ float event_elapsed_ms(Event*, Event*) { return 0.f; }
 
 typedef TfRowsBT<TF_B2> TfRowsUp;
 
+unsigned kernel_block(Module*, int) { return 64; }     // (the walks run in their one-wavefront form here)
 void launch(Module*, int kernel, unsigned gx, unsigned gy, unsigned block,
             const void* args, size_t, Stream*, unsigned) {
     const int64_t nthreads = (int64_t)gx * block;

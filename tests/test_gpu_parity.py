@@ -458,6 +458,45 @@ def test_walks_assemble_the_separator_rows(cfg, sch, N, nsys, monkeypatch):
     assert np.isfinite(out[0]).all() and err <= 1e-10, err
 
 
+@pytest.mark.parametrize("name,N,periodic", [("M3_film", 3001, True), ("M3_film", 2003, False), ("bivar", 1501, False)])
+def test_split_factorisation_walk_equals_one_wavefront(name, N, periodic, monkeypatch):
+    """tfk_l1_factor* by two wavefronts per 64 chunks and direction (one eliminates the band, the
+    other carries the spike columns and the first right-hand side with the pivot blocks published
+    in LDS; TF_L1_SPLIT_MODEL) does the arithmetic of the one-wavefront walk: the same products in
+    the same order -- solutions equal to the last bits, with the stored spike response and with
+    the second elimination, and in steps whose first solve rides with the factorisation."""
+    from triflow_amd import compilers
+    from triflow_amd.ensemble import Ensemble
+    rng = np.random.default_rng(17)
+    fd = corpus.synthetic_fields(name, N, seed=5, periodic=periodic, length=N * 5e-3)
+    pars = corpus.synthetic_pars(name, N, periodic)
+    rhs = rng.standard_normal(N * len(corpus.model_args(name)[1]))
+    results = {}
+    for form in ("split", "one"):
+        if form == "one":
+            monkeypatch.setattr(compilers, "HIPCC_FLAGS", compilers.HIPCC_FLAGS + ["-DTF_L1_SPLIT=0"])
+        m = pc.device_model(name, HIP)
+        xs = []
+        for respike in ("0", "1"):
+            monkeypatch.setenv("TRIFLOW_L1_RESPIKE", respike)
+            solver = pc.bound_solver(m, fd, pars)
+            assert solver.kernel_block("tfk_l1_factor_rhs") == (128 if form == "split" else 64)
+            solver.eval(0, with_j=True)
+            solver.factor(0.01)
+            xs.append(solver.solve(rhs)[0].copy())
+            ens = Ensemble(m, fd["x"], {k: v for k, v in fd.items() if k != "x"}, pars, periodic,
+                           scheme="ROS2", nstate=2, refine=0)
+            for _ in range(3):
+                ens.step(1e-3)
+            ens.sync()
+            xs.append(ens.state().copy())
+            ens.close()
+        results[form] = xs
+    for a, b in zip(results["split"], results["one"]):
+        err = np.abs(a - b).max() / np.abs(b).max()
+        assert np.isfinite(a).all() and err <= 1e-13, err
+
+
 def test_ensemble_restart():
     pc.check_ensemble_restart(HIP)
 

@@ -1,4 +1,4 @@
-"""In-kernel phase timing of the reduced-level factorisation (diagnostic build -DTF_STAMPS):
+"""In-kernel phase timing of the level-1 walks and of the reduced-level factorisation (diagnostic build -DTF_STAMPS):
 shader-clock stamps of one workgroup per level, printed as cycles per phase."""
 import os, sys
 os.environ["TRIFLOW_HIPCC_EXTRA"] = (os.environ.get("TRIFLOW_HIPCC_EXTRA", "") + " -DTF_STAMPS").strip()
@@ -23,6 +23,19 @@ for _ in range(5):
 ens.sync()
 st = s.debug_stamps().astype(np.int64)
 print("levels", s.describe()["chunks"])
+r = st[0]
+if r[10]:
+    print("level 1, factorisation walk (down, band wavefront): first rows %d | %d nodes of the loop %d (one node: %d) | tip pivots, tips, separator row %d cycles"
+          % (r[11] - r[10], s.describe()["chunks"][0] and 0 or 0, r[12] - r[11], r[15] - r[14], r[13] - r[12]))
+if r[30]:
+    print("         right-hand side wavefront, relative to the band wavefront's entry: entry %d, loop from %d to %d, barriers passed %d, tips and separator row done %d | band wavefront: tips done %d, last barrier passed %d, records stored %d"
+          % (r[30] - r[10], r[31] - r[10], r[32] - r[10], r[33] - r[10], r[34] - r[10], r[13] - r[10], r[16] - r[10], r[17] - r[10]))
+if r[0]:
+    print("level 1, re-elimination + back-substitution (down half): first rows %d | loop %d (one node: %d) | barrier %d | to the middle system %d | its solve %d | back-substitution %d cycles"
+          % (r[1] - r[0], r[2] - r[1], r[5] - r[4], r[3] - r[2], r[6] - r[3], r[7] - r[6], r[8] - r[7]))
+if r[20]:
+    print("level 1, first solve walk (down): first rows %d | loop %d (one node: %d) | tips %d cycles"
+          % (r[21] - r[20], r[22] - r[21], r[25] - r[24], r[23] - r[22]))
 for l in range(1, len(s.describe()["chunks"])):
     r = st[l]
     if r[0] == 0:

@@ -90,6 +90,7 @@ SIGNATURES = {
     "tf_timing_reset": (C.c_int, [C.c_void_p]),
     "tf_timing_get": (C.c_int, [C.c_void_p, C.c_int32, c_double_p, c_int64_p]),
     "tf_debug_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int32]),
+    "tf_solver_kernel_block": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "tf_kernel_count": (C.c_int, []),
     "tf_kernel_name": (C.c_char_p, [C.c_int32]),
 }
@@ -411,6 +412,12 @@ class DeviceSolver:
         f, c, r = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         self.lib.call("tf_solver_counters", self.handle, C.byref(f), C.byref(c), C.byref(r))
         return dict(factorisations=f.value, checks=c.value, replans=r.value)
+
+    def kernel_block(self, name):
+        """Workgroup size the kernel ``name`` of the model's code object was built for."""
+        b = C.c_int32(0)
+        self.lib.call("tf_solver_kernel_block", self.handle, self.lib.kernel_names().index(name), C.byref(b))
+        return b.value
 
     def monitor_error(self):
         """Worst backward error seen by the in-pass monitor of the Rosenbrock steps since the last

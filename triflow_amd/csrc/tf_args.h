@@ -266,6 +266,19 @@ struct TfTopArgs {                 // final 1-node system per ensemble member
 // ... in twisted form while one walk direction leaves SIMDs idle (1024 SIMDs x 64 lanes)
 #define TF_TWIST_MAX_CHUNKS 65536
 
+// Level-1 factorisation walks by two wavefronts per 64 chunks and direction (tf_kernels.h, ROLE):
+// one eliminates the band, the other carries the right-hand sides (the spike columns and the first
+// right-hand side of the step) with the pivot blocks the first one publishes in LDS (two slots of
+// (1 + mp) nvar^2 doubles per lane).  Each wavefront then fits 256 registers (the one-wavefront
+// form of the film model needs 374 and keeps 100 values in AGPRs) and the two share a SIMD.
+// Config 3: tfk_l1_factor_rhs 81 -> 75 us, 8 members per GPU 641 -> 600 us; the stiff model's
+// slots (51 KB) leave room for three workgroups per CU only and the exchange costs more than the
+// registers did: 488 -> 558 us, so blocks above 40 KB of slots keep the one-wavefront form
+// (profiles/r03_ab_runs.txt, r3o).  Not for scalar models (rows are exchanged there).  The code
+// object says which form it holds: the launch bound of tfk_l1_factor is 128 or 64
+// (tfb::kernel_block).
+#define TF_L1_SPLIT_MODEL(mp, nvar) ((nvar) >= 2 && 2 * (1 + (mp)) * (nvar) * (nvar) * 64 * 8 <= 40 * 1024)
+
 // nodes per thread of tfk_sweep_f_stage_rhs (the other sweeps: TF_SEG of the code object, 4 or 8).
 // Two register windows per variable make its ghost rows twice as expensive: 8 nodes per thread
 // read 152 MB where 4 read 176 MB (config 3; 43 against 51 us per launch, profiles/r02_ab_runs.txt)

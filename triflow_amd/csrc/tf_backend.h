@@ -40,6 +40,10 @@ Stream* stream_create();
 void stream_destroy(Stream* s);
 void stream_sync(Stream* s);
 
+// the workgroup size a kernel of the code object was compiled for (its launch bound): some
+// kernels exist in a one- and a two-wavefront form per model (tfk_l1_factor*)
+unsigned kernel_block(Module* m, int kernel);
+
 // one launch: grid (gx, gy, 1), block (block, 1, 1), one by-value argument struct;
 // lds_bytes: dynamic LDS of the workgroup (extern __shared__)
 void launch(Module* m, int kernel, unsigned gx, unsigned gy, unsigned block,

@@ -225,6 +225,12 @@ Stream* stream_create() {
 void stream_destroy(Stream* s) { if (s) { (void)hipStreamDestroy(s->s); delete s; } }
 void stream_sync(Stream* s) { TF_HIP(hipStreamSynchronize(s->s)); }
 
+unsigned kernel_block(Module* m, int kernel) {
+    int v = 0;
+    TF_HIP(hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_MAX_THREADS_PER_BLOCK, m->fn[kernel]));
+    return (unsigned)v;
+}
+
 void launch(Module* m, int kernel, unsigned gx, unsigned gy, unsigned block,
             const void* args, size_t arg_bytes, Stream* s, unsigned lds_bytes) {
     size_t size = arg_bytes;

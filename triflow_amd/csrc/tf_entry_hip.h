@@ -15,26 +15,50 @@
 #define TF_ASM_HALF (2 * TF_B2 * TF_B2)
 #define TF_ASM_SW (TF_ASM_HALF | 1)                  // odd stride: no bank conflicts
 #define TF_FUSE_ASM_OK (TF_ASM_SW * 64 * 8 <= 40 * 1024)
+#ifndef TF_L1_SPLIT
+#define TF_L1_SPLIT 1              // 0: one wavefront per 64 chunks and direction (A/B runs)
+#endif
+#define TF_L1_SPLIT_ON (TF_L1_SPLIT && TF_L1_SPLIT_MODEL(TF_MP, TF_NVAR))
+#define TF_L1_FACTOR_BLOCK (TF_L1_SPLIT_ON ? 128 : 64)
+#define TF_L1_XCH (TF_L1_SPLIT_ON ? 2 * (1 + TF_MP) * TF_NVAR * TF_NVAR * 64 : 1)
+#define TF_L1_STAGE (TF_FUSE_ASM_OK ? 64 * TF_ASM_SW : 1)
 template <bool WITH_RHS>
 __device__ __forceinline__ void tfk_l1_factor_any(const TfLevelArgs& a) {
-    __shared__ double stage[TF_FUSE_ASM_OK ? 64 * TF_ASM_SW : 1];
+    // (the exchange slots of a split walk and the stage of the separator rows share the block:
+    // the last slot is read before the first row is staged)
+    __shared__ double stage[TF_L1_STAGE > TF_L1_XCH ? TF_L1_STAGE : TF_L1_XCH];
     __shared__ int srec[64];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, role = threadIdx.x >> 6, pg = blockIdx.x * 64 + lane;
     const bool fuse = TF_FUSE_ASM_OK && a.fuse_asm;
     double* st = fuse ? stage + lane * TF_ASM_SW : nullptr;
     int rec = -1;
-    if (blockIdx.y == 0) tfk_chunk_body<TfRowsL1, +1, true, true, WITH_RHS>(a, TF_GID, nullptr, st, &rec);
-    else tfk_chunk_body<TfRowsL1, -1, true, TF_RESPIKE_MODEL(TF_MP, TF_NVAR), false>(a, TF_GID, nullptr, st, &rec);
+    TF_WGTRACE(a, 0, 0);
+    constexpr bool UP_U = TF_RESPIKE_MODEL(TF_MP, TF_NVAR);
+    if constexpr (TF_L1_SPLIT_ON) {
+        if (role == 0) {
+            if (blockIdx.y == 0) tfk_chunk_body<TfRowsL1, +1, true, true, false, false, false, 1>(a, pg, nullptr, st, &rec, stage + lane);
+            else tfk_chunk_body<TfRowsL1, -1, true, UP_U, false, false, false, 1>(a, pg, nullptr, st, &rec, stage + lane);
+        } else {
+            if (blockIdx.y == 0) tfk_rhs_follow_body<TfRowsL1, +1, true, WITH_RHS>(a, pg, stage + lane, st);
+            else tfk_rhs_follow_body<TfRowsL1, -1, UP_U, false>(a, pg, stage + lane, st);
+        }
+    } else {
+        if (blockIdx.y == 0) tfk_chunk_body<TfRowsL1, +1, true, true, WITH_RHS>(a, pg, nullptr, st, &rec);
+        else tfk_chunk_body<TfRowsL1, -1, true, UP_U, false>(a, pg, nullptr, st, &rec);
+    }
     if (fuse) {
-        srec[lane] = rec;
+        if (role == 0) srec[lane] = rec;
         __syncthreads();
+        TF_STAMP_T(a, 16, 0);
         const int side = blockIdx.y == 0 ? 0 : TF_ASM_HALF;       // [sub, dia | sup, second part of dia]
-        for (int idx = lane; idx < 64 * TF_ASM_HALF; idx += 64) {
+        for (int idx = threadIdx.x; idx < 64 * TF_ASM_HALF; idx += TF_L1_FACTOR_BLOCK) {
             const int t = idx / TF_ASM_HALF, off = idx - t * TF_ASM_HALF;
             const int r = srec[t];
             if (r >= 0) a.Anext[(int64_t)r * 2 * TF_ASM_HALF + side + off] = stage[t * TF_ASM_SW + off];
         }
     }
+    TF_STAMP_T(a, 17, 0);
+    TF_WGTRACE(a, 0, 1);
 }
 
 extern "C" {
@@ -167,13 +191,28 @@ __global__ void __launch_bounds__(64) tfk_poke(TfPokeArgs a) {
 
 // ---- banded solver, level 1 (rows from the Jacobian planes) ----------------
 // grid.y: 0 = walk down, 1 = walk up (wave-uniform)
-__global__ void __launch_bounds__(64) tfk_l1_factor(TfLevelArgs a) { tfk_l1_factor_any<false>(a); }
+// TF_L1_WAVES (A/B runs): ask the compiler for that many wavefronts per SIMD in the walks (the
+// window of a walk lives in registers: the film model's factorisation takes 356 of a lane's 512)
+#ifdef TF_L1_WAVES
+#define TF_L1_ATTR __attribute__((amdgpu_waves_per_eu(TF_L1_WAVES, TF_L1_WAVES)))
+#else
+#define TF_L1_ATTR
+#endif
+// the two wavefronts of a split factorisation walk share a SIMD: half the registers each
+#if !defined(TF_L1_WAVES) && TF_L1_SPLIT_ON
+#define TF_L1_FACTOR_ATTR __attribute__((amdgpu_waves_per_eu(2)))
+#else
+#define TF_L1_FACTOR_ATTR TF_L1_ATTR
+#endif
+__global__ void TF_L1_FACTOR_ATTR __launch_bounds__(TF_L1_FACTOR_BLOCK) tfk_l1_factor(TfLevelArgs a) { tfk_l1_factor_any<false>(a); }
 // factorisation that also eliminates a first right-hand side (the first solve of a
 // time step rides along: no second walk over J for it)
-__global__ void __launch_bounds__(64) tfk_l1_factor_rhs(TfLevelArgs a) { tfk_l1_factor_any<true>(a); }
+__global__ void TF_L1_FACTOR_ATTR __launch_bounds__(TF_L1_FACTOR_BLOCK) tfk_l1_factor_rhs(TfLevelArgs a) { tfk_l1_factor_any<true>(a); }
 __global__ void __launch_bounds__(64) tfk_l1_solve(TfLevelArgs a) {
+    TF_WGTRACE(a, 2, 0);
     if (blockIdx.y == 0) tfk_chunk_body<TfRowsL1, +1, false, false, true>(a, TF_GID);
     else tfk_chunk_body<TfRowsL1, -1, false, false, false>(a, TF_GID);
+    TF_WGTRACE(a, 2, 1);
 }
 // Second elimination of a right-hand side, once the separators are solved: the values of the
 // separator behind a walk go to the right-hand side of its first rows, the elimination is
@@ -194,16 +233,20 @@ __global__ void __launch_bounds__(64) tfk_l1_fwd2(TfLevelArgs a) {
 // ([direction][row][b][lane]: 49 KB for the film model), the barrier hands the rows next to the
 // middle to the other direction, and the back-substitution starts from there: 8 bytes per node and
 // variable less written, and read, per solve, and one launch less.
-__global__ void __launch_bounds__(128) tfk_l1_fwd2_backsub(TfLevelArgs a) {
+__global__ void TF_L1_ATTR __launch_bounds__(128) tfk_l1_fwd2_backsub(TfLevelArgs a) {
     if constexpr (TF_RESPIKE_MODEL(TF_MP, TF_NVAR)) {
         extern __shared__ double tf_dyn_lds[];
+        TF_WGTRACE(a, 1, 0);
         const int lane = threadIdx.x & 63, dir = threadIdx.x >> 6, pg = blockIdx.x * 64 + lane;
         double* ydn = tf_dyn_lds + lane;
         double* yup = tf_dyn_lds + (size_t)a.ylds_rows * TF_NVAR * 64 + lane;
         if (dir == 0) tfk_chunk_body<TfRowsL1, +1, false, false, true, true, true>(a, pg, ydn);
         else tfk_chunk_body<TfRowsL1, -1, false, false, true, true, true>(a, pg, yup);
         __syncthreads();
+        TF_STAMP(a, 3);
         tfk_backsub_twist_body<TfRowsL1, true>(a, pg, dir, ydn, yup);
+        TF_STAMP(a, 8);
+        TF_WGTRACE(a, 1, 1);
     }
 }
 // The next level's rows.  When that level keeps records per node (cyclic reduction), the 64
@@ -238,8 +281,8 @@ __global__ void __launch_bounds__(64 * TF_MP) tfk_l1_asm_rhs(TfLevelArgs a) {
     tfk_asm_body<TfRowsL1, false>(a, blockIdx.x * 64 + (threadIdx.x & 63), nullptr,
                                   blockDim.x > 64 ? (int)(threadIdx.x >> 6) : -1);
 }
-__global__ void __launch_bounds__(64) tfk_l1_backsub(TfLevelArgs a) { tfk_backsub_body<TfRowsL1, true>(a, TF_GID); }
-__global__ void __launch_bounds__(64) tfk_l1_backsub_u(TfLevelArgs a) {
+__global__ void TF_L1_ATTR __launch_bounds__(64) tfk_l1_backsub(TfLevelArgs a) { tfk_backsub_body<TfRowsL1, true>(a, TF_GID); }
+__global__ void TF_L1_ATTR __launch_bounds__(64) tfk_l1_backsub_u(TfLevelArgs a) {
     if constexpr (TF_RESPIKE_MODEL(TF_MP, TF_NVAR)) tfk_backsub_twist_body<TfRowsL1>(a, TF_GID, (int)blockIdx.y);
 }
 

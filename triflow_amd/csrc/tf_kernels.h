@@ -44,14 +44,34 @@
 #if defined(TF_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
 #define TF_STAMP(a, i) do { if ((a).stamps && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) \
         (a).stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TF_STAMP_T(a, i, tid) do { if ((a).stamps && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && threadIdx.x == (tid)) \
+        (a).stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #define TF_STAMP_REAL(a, i) do { if ((a).stamps && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) \
         (a).stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 // ... and event counters (every workgroup; one lane per wavefront counts)
 #define TF_COUNT(a, i) do { if ((a).stamps && (threadIdx.x & 63) == 0) atomicAdd(&(a).stamps[i], 1ull); } while (0)
+// ... and begin / end times (100 MHz) of every workgroup of a level-1 kernel: region k of 2048
+// entries behind the 8 level regions (tools/gpu_wgtrace.py asks for that many)
+#define TF_WGTRACE(a, k, which) do { if ((a).stamps && threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < 1024) \
+        (a).stamps[512 + 2048 * (k) + 2 * (blockIdx.y * gridDim.x + blockIdx.x) + (which)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
+#define TF_WGTRACE(a, k, which) do {} while (0)
 #define TF_STAMP(a, i) do {} while (0)
+#define TF_STAMP_T(a, i, tid) do {} while (0)
 #define TF_STAMP_REAL(a, i) do {} while (0)
 #define TF_COUNT(a, i) do {} while (0)
+#endif
+
+// (level-1 walks: the down walk of the middle workgroup; slots 0.. re-elimination, 10.. factorisation,
+// 20.. first solve walk)
+#define TF_STAMP_L1(a, dir, i) do { if ((dir) > 0 && blockIdx.y == 0) TF_STAMP(a, i); } while (0)
+
+// workgroup barrier of the kernels whose wavefronts work together (the emulation runs the
+// one-wavefront forms of those: nothing to wait for)
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+#define TF_WG_BARRIER() __syncthreads()
+#else
+#define TF_WG_BARRIER() do {} while (0)
 #endif
 
 // ------------------------------------------------------------------- layout
@@ -875,13 +895,17 @@ TF_DEVICE int tf_twist_h(int mI, int enabled) {
 // tfk_l1_asm_mat / tfk_l1_asm_rhs launch (profiles/r03_ab_runs.txt).  `stage`: this lane's
 // [2][b][b] part of the record (LDS, written out as whole records by the kernel); *rec = the
 // record (node of the next level) it belongs to, -1 = none.
-template <class Rows, int DIR, bool MATRIX>
+template <class Rows, int DIR, bool MATRIX, bool DO_V = true, bool DO_W = true, bool DO_G = true>
 TF_DEVICE void tf_asm_side(const TfLevelArgs& a, const Rows& own, int pg,
                            const double (&yN)[Rows::MP][Rows::B],
                            const double (&VN)[MATRIX ? Rows::MP : 1][MATRIX ? Rows::MP : 1][Rows::B][Rows::B],
                            const double (&WN)[MATRIX ? Rows::MP : 1][MATRIX ? Rows::MP : 1][Rows::B][Rows::B],
                            double* stage, int* rec) {
+    // DO_V / DO_W / DO_G (split walks, tfk_chunk_body ROLE): the block that takes the products
+    // with V (down: sub, up: second part of dia), the one that takes those with W (down: dia,
+    // up: sup) and the right-hand side are not all made by the same wavefront
     constexpr int B = Rows::B, MP = Rows::MP, W = 2 * MP + 1, BB = MP * B;
+    constexpr int VBLK = DIR > 0 ? 0 : 1, WBLK = 1 - VBLK;
     const TfLayout& L = a.L;
     const int e = own.e, p = own.p;
     const bool has = DIR > 0 || L.periodic || p > 0;
@@ -896,47 +920,38 @@ TF_DEVICE void tf_asm_side(const TfLevelArgs& a, const Rows& own, int pg,
     for (int t = 0; t < MP; ++t) {                 // separator node t = node mIs + t of chunk ps
         double row[W][B][B];
         rs.load(mIs + t, row);
-        double A1[MP][B][B], A2[MP][B][B], g[B];   // down: sub, dia      up: sup, second part of dia
+        double AV[MP][B][B], AW[MP][B][B], g[B];
 #pragma unroll
-        for (int t2 = 0; t2 < MP; ++t2) { tf_blk_zero<B>(A1[t2]); tf_blk_zero<B>(A2[t2]); }
+        for (int t2 = 0; t2 < MP; ++t2) { tf_blk_zero<B>(AV[t2]); tf_blk_zero<B>(AW[t2]); }
         const int64_t s = tf_idx(L, pgs, mIs + t);
 #pragma unroll
-        for (int r = 0; r < B; ++r) g[r] = (DIR > 0 && a.rhs) ? a.rhs[(int64_t)r * L.plane + s] : 0.0;
+        for (int r = 0; r < B; ++r) g[r] = (DO_G && DIR > 0 && a.rhs) ? a.rhs[(int64_t)r * L.plane + s] : 0.0;
 #pragma unroll
         for (int d = -MP; d <= MP; ++d) {
             const int cn = t + d;                  // column relative to the separator start
-            if (DIR > 0) {
-                if (cn >= 0 && cn < MP) {
-                    if (MATRIX) {
+            // down: the bottom tip node cn + MP of the own interior; up: the top tip node cn - MP
+            // of the interior below
+            const bool tip = DIR > 0 ? cn < 0 : cn >= MP;
+            const int kt = DIR > 0 ? cn + MP : cn - MP;
+            if (DIR > 0 && cn >= 0 && cn < MP) {
+                if (MATRIX && DO_W) {
 #pragma unroll
-                        for (int r = 0; r < B; ++r)
+                    for (int r = 0; r < B; ++r)
 #pragma unroll
-                            for (int c = 0; c < B; ++c) A2[cn][r][c] += row[d + MP][r][c];
-                    }
-                } else if (cn < 0) {               // bottom tip node kb of the own interior
-                    const int kb = cn + MP;
-                    tf_mv_sub<B>(g, row[d + MP], yN[kb]);
-                    if (MATRIX) {
-#pragma unroll
-                        for (int t2 = 0; t2 < MP; ++t2) {
-                            tf_mm_sub<B>(A1[t2], row[d + MP], VN[MATRIX ? kb : 0][MATRIX ? t2 : 0]);
-                            tf_mm_sub<B>(A2[t2], row[d + MP], WN[MATRIX ? kb : 0][MATRIX ? t2 : 0]);
-                        }
-                    }
+                        for (int c = 0; c < B; ++c) AW[cn][r][c] += row[d + MP][r][c];
                 }
-            } else if (cn >= MP) {                 // top tip node kt of the interior below
-                const int kt = cn - MP;
-                tf_mv_sub<B>(g, row[d + MP], yN[kt]);
+            } else if (tip) {
+                if (DO_G) tf_mv_sub<B>(g, row[d + MP], yN[kt]);
                 if (MATRIX) {
 #pragma unroll
                     for (int t2 = 0; t2 < MP; ++t2) {
-                        tf_mm_sub<B>(A2[t2], row[d + MP], VN[MATRIX ? kt : 0][MATRIX ? t2 : 0]);
-                        tf_mm_sub<B>(A1[t2], row[d + MP], WN[MATRIX ? kt : 0][MATRIX ? t2 : 0]);
+                        if (DO_V) tf_mm_sub<B>(AV[t2], row[d + MP], VN[MATRIX ? kt : 0][MATRIX ? t2 : 0]);
+                        if (DO_W) tf_mm_sub<B>(AW[t2], row[d + MP], WN[MATRIX ? kt : 0][MATRIX ? t2 : 0]);
                     }
                 }
             }
         }
-        if (a.rhs) {
+        if (DO_G && a.rhs) {
 #pragma unroll
             for (int r = 0; r < B; ++r)
                 a.rhsnext[(int64_t)r_next * 2 * BB + (DIR > 0 ? 0 : BB) + t * B + r] = g[r];
@@ -949,9 +964,115 @@ TF_DEVICE void tf_asm_side(const TfLevelArgs& a, const Rows& own, int pg,
 #pragma unroll
                     for (int c = 0; c < B; ++c) {
                         const int rr = t * B + r, cc = t2 * B + c;
-                        stage[(0 * BB + rr) * BB + cc] = A1[t2][r][c];
-                        stage[(1 * BB + rr) * BB + cc] = A2[t2][r][c];
+                        if (DO_V) stage[(VBLK * BB + rr) * BB + cc] = AV[t2][r][c];
+                        if (DO_W) stage[(WBLK * BB + rr) * BB + cc] = AW[t2][r][c];
                     }
+        }
+    }
+}
+
+// ---- tips: back-substitute the last MP pivots (local k = 0..MP-1 <-> local node mI-MP+k);
+// unknowns beyond the interior are the separator ahead.
+//   x_k = yb_k - sum_t Vb[k][t] s_behind[t] - sum_t Wb[k][t] s_ahead[t]
+// and leave them in natural orientation: in memory (tips_dn / tips_up) or, with a.fuse_asm, as
+// this walk's half of the separator's row.  DO_V / DO_WY: the part made by this wavefront (both,
+// or one each in a split walk).
+template <class Rows, int DIR, bool SPIKE, bool DO_V, bool DO_W, bool DO_Y, int UW, int NE>
+TF_DEVICE void tf_tips_out(const TfLevelArgs& a, const Rows& rows, int pg,
+                           const double (&Uh)[Rows::MP][UW][Rows::B][Rows::B], const double (&yh)[Rows::MP][Rows::B],
+                           const double (&Eh)[NE][NE][Rows::B][Rows::B],      // NE = SPIKE ? MP : 1
+                           double* asm_stage, int* asm_rec) {
+    constexpr int B = Rows::B, MP = Rows::MP;
+    typedef TfTips<B, MP> Tip;
+    const TfLayout& L = a.L;
+    double yb[MP][B];
+    double Vb[SPIKE ? MP : 1][SPIKE ? MP : 1][B][B], Wb[SPIKE ? MP : 1][SPIKE ? MP : 1][B][B];
+#pragma unroll
+    for (int k = MP - 1; k >= 0; --k) {
+#pragma unroll
+        for (int r = 0; r < B; ++r) yb[k][r] = DO_Y ? yh[k][r] : 0.0;
+        if (SPIKE) {
+#pragma unroll
+            for (int t = 0; t < MP; ++t) {
+                if (DO_V) tf_blk_copy<B>(Vb[SPIKE ? k : 0][SPIKE ? t : 0], Eh[SPIKE ? k : 0][SPIKE ? t : 0]);
+                else tf_blk_zero<B>(Vb[SPIKE ? k : 0][SPIKE ? t : 0]);
+                tf_blk_zero<B>(Wb[SPIKE ? k : 0][SPIKE ? t : 0]);
+            }
+        }
+#pragma unroll
+        for (int c = 1; c <= UW; ++c) {
+            const int kk = k + c;
+            if (kk >= 2 * MP) {
+                // beyond the separator ahead: no interior row reaches there, the
+                // (exchanged) pivot row holds an exact zero
+            } else if (kk < MP) {
+                if (DO_Y) tf_mv_sub<B>(yb[k], Uh[k][c - 1], yb[kk]);
+                if (SPIKE) {
+#pragma unroll
+                    for (int t = 0; t < MP; ++t) {
+                        if (DO_V) tf_mm_sub<B>(Vb[SPIKE ? k : 0][SPIKE ? t : 0], Uh[k][c - 1], Vb[SPIKE ? kk : 0][SPIKE ? t : 0]);
+                        if (DO_W) tf_mm_sub<B>(Wb[SPIKE ? k : 0][SPIKE ? t : 0], Uh[k][c - 1], Wb[SPIKE ? kk : 0][SPIKE ? t : 0]);
+                    }
+                }
+            } else if (SPIKE && DO_W) {
+                const int t = kk - MP;                  // separator ahead, local position t
+#pragma unroll
+                for (int r = 0; r < B; ++r)
+#pragma unroll
+                    for (int cc = 0; cc < B; ++cc) Wb[SPIKE ? k : 0][SPIKE ? t : 0][r][cc] += Uh[k][c - 1][r][cc];
+            }
+        }
+    }
+
+    if (a.fuse_asm) {
+        // the tips in natural orientation stay in registers: this walk's half of the separator's row
+        // (down: behind = above (V), ahead = below (W); up: the reverse)
+        double yN[MP][B];
+        double VN[SPIKE ? MP : 1][SPIKE ? MP : 1][B][B], WN[SPIKE ? MP : 1][SPIKE ? MP : 1][B][B];
+#pragma unroll
+        for (int k = 0; k < MP; ++k) {
+            const int kn = DIR > 0 ? k : MP - 1 - k;
+#pragma unroll
+            for (int r = 0; r < B; ++r) yN[kn][r] = yb[k][r];
+            if (SPIKE) {
+#pragma unroll
+                for (int t = 0; t < MP; ++t) {
+                    const int tn = DIR > 0 ? t : MP - 1 - t;
+                    tf_blk_copy<B>(VN[SPIKE ? kn : 0][SPIKE ? tn : 0], DIR > 0 ? Vb[SPIKE ? k : 0][SPIKE ? t : 0] : Wb[SPIKE ? k : 0][SPIKE ? t : 0]);
+                    tf_blk_copy<B>(WN[SPIKE ? kn : 0][SPIKE ? tn : 0], DIR > 0 ? Wb[SPIKE ? k : 0][SPIKE ? t : 0] : Vb[SPIKE ? k : 0][SPIKE ? t : 0]);
+                }
+            }
+        }
+        // (in natural orientation the walk's V is the row's V going down and its W going up)
+        constexpr bool DOWN = (DIR > 0), NAT_V = DOWN ? DO_V : DO_W, NAT_W = DOWN ? DO_W : DO_V;
+        tf_asm_side<Rows, DIR, SPIKE, NAT_V, NAT_W, DO_Y>(a, rows, pg, yN, VN, WN, asm_stage, asm_rec);
+        return;
+    }
+    // ---- write in natural orientation
+    double* tips = DIR > 0 ? a.tips_dn : a.tips_up;
+    auto put = [&](int slot, double v) { tips[(int64_t)slot * L.Ptot + pg] = v; };
+#pragma unroll
+    for (int k = 0; k < MP; ++k) {
+        const int kn = DIR > 0 ? k : MP - 1 - k;        // natural tip index
+        if (DO_Y) {
+#pragma unroll
+            for (int r = 0; r < B; ++r) put(Tip::y(kn, r), yb[k][r]);
+        }
+        if (SPIKE) {
+#pragma unroll
+            for (int t = 0; t < MP; ++t) {
+                const int tn = DIR > 0 ? t : MP - 1 - t;
+#pragma unroll
+                for (int r = 0; r < B; ++r)
+#pragma unroll
+                    for (int c = 0; c < B; ++c) {
+                        // down: behind = above (V), ahead = below (W); up: the reverse
+                        const double vb = Vb[SPIKE ? k : 0][SPIKE ? t : 0][r][c];
+                        const double wb = Wb[SPIKE ? k : 0][SPIKE ? t : 0][r][c];
+                        if (DO_V) put(DIR > 0 ? Tip::V(kn, tn, r, c) : Tip::W(kn, tn, r, c), vb);
+                        if (DO_W) put(DIR > 0 ? Tip::W(kn, tn, r, c) : Tip::V(kn, tn, r, c), wb);
+                    }
+            }
         }
     }
 }
@@ -971,17 +1092,29 @@ TF_DEVICE void tf_asm_side(const TfLevelArgs& a, const Rows& own, int pg,
 // (YLDS is a flag, not a null test of the pointer: testing an LDS pointer against NULL trips
 // hipcc 7.2 on some models, "Illegal instruction detected: V_CMP_NE_U32 0, $src_shared_base")
 // asm_stage / asm_rec (a.fuse_asm): where tf_asm_side puts this walk's part of a separator's row.
-template <class Rows, int DIR, bool SPIKE, bool STORE_U, bool STORE_Y, bool KNOWN = false, bool YLDS = false>
+// ROLE = 1 (tfk_l1_factor*, two wavefronts per 64 chunks and direction): this walk eliminates the
+// band only and publishes, per pivot, the inverse of the pivot block and the blocks below it to
+// `xch` (LDS, element k of slot j & 1 at xch[(slot * NX + k) * 64]); the wavefront next to it
+// (tfk_rhs_follow_body) carries every right-hand side with them -- the spike columns and the
+// first right-hand side of the step -- and makes their tips (V, y); this one makes W.  One
+// barrier per pivot.  (STORE_Y is false here: nothing uses y, the compiler drops it.)
+template <class Rows, int DIR, bool SPIKE, bool STORE_U, bool STORE_Y, bool KNOWN = false, bool YLDS = false,
+          int ROLE = 0>
 TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg, double* ylds = nullptr,
-                              double* asm_stage = nullptr, int* asm_rec = nullptr) {
+                              double* asm_stage = nullptr, int* asm_rec = nullptr, double* xch = nullptr) {
     constexpr int B = Rows::B, MP = Rows::MP, W = 2 * MP + 1;
     static_assert(!KNOWN || (!SPIKE && !STORE_U), "the re-elimination takes one right-hand side");
+    static_assert(ROLE == 0 || (SPIKE && !STORE_Y && !Rows::PIVOT), "the split walk carries spike columns and exchanges no rows");
+    constexpr bool ES = SPIKE && ROLE == 0;       // the spike columns are eliminated by this walk
+    constexpr int NX = (1 + MP) * B * B;          // doubles published per pivot (ROLE 1)
     constexpr bool PIV = Rows::PIVOT;             // row exchanges inside the window (B == 1)
     constexpr int UW = PIV ? 2 * MP : MP;         // blocks right of the pivot kept in U
     static_assert(!PIV || B == 1, "row exchanges are written for scalar blocks");
     typedef TfTips<B, MP> Tip;
     const TfLayout& L = a.L;
     if (pg >= L.Ptot) return;
+    constexpr int SB = KNOWN ? 0 : (SPIKE ? 10 : 20);   // stamps (diagnostic builds)
+    TF_STAMP_L1(a, DIR, SB + 0);
     Rows rows(a, pg);
     const int len = rows.len;
     const int mI = len - MP;                      // interior nodes
@@ -990,7 +1123,7 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg, double* ylds = nullp
     // working window: R[q][c] = A(local row j+q, local col j+c)
     double R[MP + 1][W][B][B];
     double y[MP + 1][B];
-    double Es[SPIKE ? MP + 1 : 1][SPIKE ? MP : 1][B][B];   // columns: separator behind, local order
+    double Es[ES ? MP + 1 : 1][ES ? MP : 1][B][B];   // columns: separator behind, local order
     // normalised rows of the last MP pivots (tips)
     double Uh[MP][UW][B][B], yh[MP][B];
     double Eh[SPIKE ? MP : 1][SPIKE ? MP : 1][B][B];
@@ -1033,9 +1166,9 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg, double* ylds = nullp
         for (int c = 0; c < W; ++c) tf_blk_zero<B>(R[q][c]);
 #pragma unroll
         for (int r = 0; r < B; ++r) y[q][r] = 0.0;
-        if (SPIKE) {
+        if (ES) {
 #pragma unroll
-            for (int t = 0; t < MP; ++t) tf_blk_zero<B>(Es[SPIKE ? q : 0][SPIKE ? t : 0]);
+            for (int t = 0; t < MP; ++t) tf_blk_zero<B>(Es[ES ? q : 0][ES ? t : 0]);
         }
         if (jl < mI) {
             double row[W][B][B];
@@ -1048,10 +1181,10 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg, double* ylds = nullp
                 const int dd = DIR > 0 ? d : -d;   // natural offset
                 if (c >= 0) {
                     if (c < W) tf_blk_copy<B>(R[q][c], row[dd + MP]);
-                } else if (SPIKE) {
+                } else if (ES) {
                     // column jl + d < 0: separator behind, local position MP + (jl + d)
                     const int t = MP + jl + d;
-                    if (t >= 0 && t < MP) tf_blk_copy<B>(Es[SPIKE ? q : 0][SPIKE ? t : 0], row[dd + MP]);
+                    if (t >= 0 && t < MP) tf_blk_copy<B>(Es[ES ? q : 0][ES ? t : 0], row[dd + MP]);
                 } else if (KNOWN) {
                     const int t = MP + jl + d;
                     if (t >= 0 && t < MP) tf_mv_sub<B>(y[q], row[dd + MP], sa[KNOWN ? t : 0]);
@@ -1074,6 +1207,7 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg, double* ylds = nullp
 
 #pragma unroll
     for (int q = 0; q < MP; ++q) fetch(q, q);
+    TF_STAMP_L1(a, DIR, SB + 1);
 
     // one pivot; HIST >= 0 also records the normalised row as tip history slot HIST
     // (only the last MP pivots are recorded, in a peeled epilogue, so that the
@@ -1097,11 +1231,11 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg, double* ylds = nullp
                     R[0][c][0][0] = sw ? v : u; R[q][c][0][0] = sw ? u : v;
                 }
                 { const double u = y[0][0], v = y[q][0]; y[0][0] = sw ? v : u; y[q][0] = sw ? u : v; }
-                if (SPIKE) {
+                if (ES) {
 #pragma unroll
                     for (int t = 0; t < MP; ++t) {
-                        const double u = Es[0][SPIKE ? t : 0][0][0], v = Es[SPIKE ? q : 0][SPIKE ? t : 0][0][0];
-                        Es[0][SPIKE ? t : 0][0][0] = sw ? v : u; Es[SPIKE ? q : 0][SPIKE ? t : 0][0][0] = sw ? u : v;
+                        const double u = Es[0][ES ? t : 0][0][0], v = Es[ES ? q : 0][ES ? t : 0][0][0];
+                        Es[0][ES ? t : 0][0][0] = sw ? v : u; Es[ES ? q : 0][ES ? t : 0][0][0] = sw ? u : v;
                     }
                 }
             }
@@ -1112,20 +1246,38 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg, double* ylds = nullp
 #pragma unroll
             for (int c = 1; c <= UW; ++c) tf_mm<B>(Un[c - 1], Dinv, R[0][c]);
             tf_mv<B>(yn, Dinv, y[0]);
-            if (SPIKE) {
+            if (ES) {
 #pragma unroll
-                for (int t = 0; t < MP; ++t) tf_mm<B>(En[t], Dinv, Es[0][t]);
+                for (int t = 0; t < MP; ++t) tf_mm<B>(En[t], Dinv, Es[0][ES ? t : 0]);
+            }
+            if (ROLE == 1) {
+                double* slot = xch + (j & 1) * (NX * 64);
+#pragma unroll
+                for (int r = 0; r < B; ++r)
+#pragma unroll
+                    for (int k = 0; k < B; ++k) slot[(r * B + k) * 64] = Dinv[r][k];
             }
         }
         if (!PIV) fetch(MP, j + MP);
+        if (ROLE == 1) {
+            // (the blocks below the pivot: the row that has just entered the window is one of them)
+            double* slot = xch + (j & 1) * (NX * 64);
+#pragma unroll
+            for (int q = 1; q <= MP; ++q)
+#pragma unroll
+                for (int r = 0; r < B; ++r)
+#pragma unroll
+                    for (int k = 0; k < B; ++k) slot[((q * B + r) * B + k) * 64] = R[q][0][r][k];
+            TF_WG_BARRIER();
+        }
 #pragma unroll
         for (int q = 1; q <= MP; ++q) {
 #pragma unroll
             for (int c = 1; c <= UW; ++c) tf_mm_sub<B>(R[q][c], R[q][0], Un[c - 1]);
             tf_mv_sub<B>(y[q], R[q][0], yn);
-            if (SPIKE) {
+            if (ES) {
 #pragma unroll
-                for (int t = 0; t < MP; ++t) tf_mm_sub<B>(Es[q][t], R[q][0], En[t]);
+                for (int t = 0; t < MP; ++t) tf_mm_sub<B>(Es[ES ? q : 0][ES ? t : 0], R[q][0], En[ES ? t : 0]);
             }
         }
         // (a.respike: E and y of the first elimination are not kept, and each walk keeps the U of
@@ -1142,8 +1294,8 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg, double* ylds = nullp
 #pragma unroll
                         for (int k = 0; k < B; ++k) {
                             tf_stp(a.Ut, (c * B + r) * B + k, L.plane, off, Un[c][r][k]);
-                            if (SPIKE && keep && c < MP)
-                                tf_stp(a.Et, (c * B + r) * B + k, L.plane, off, En[SPIKE && c < MP ? c : 0][r][k]);
+                            if (ES && keep && c < MP)
+                                tf_stp(a.Et, (c * B + r) * B + k, L.plane, off, En[ES && c < MP ? c : 0][r][k]);
                         }
             }
             if (STORE_Y && keep) {
@@ -1162,9 +1314,9 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg, double* ylds = nullp
             for (int c = 0; c < UW; ++c) tf_blk_copy<B>(Uh[H][c], Un[c]);
 #pragma unroll
             for (int r = 0; r < B; ++r) yh[H][r] = yn[r];
-            if (SPIKE) {
+            if (ES) {
 #pragma unroll
-                for (int t = 0; t < MP; ++t) tf_blk_copy<B>(Eh[SPIKE ? H : 0][SPIKE ? t : 0], En[SPIKE ? t : 0]);
+                for (int t = 0; t < MP; ++t) tf_blk_copy<B>(Eh[ES ? H : 0][ES ? t : 0], En[ES ? t : 0]);
             }
         }
         // slide the window
@@ -1175,112 +1327,181 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg, double* ylds = nullp
             tf_blk_zero<B>(R[q][W - 1]);
 #pragma unroll
             for (int r = 0; r < B; ++r) y[q][r] = y[q + 1][r];
-            if (SPIKE) {
+            if (ES) {
 #pragma unroll
-                for (int t = 0; t < MP; ++t) tf_blk_copy<B>(Es[SPIKE ? q : 0][SPIKE ? t : 0], Es[SPIKE ? q + 1 : 0][SPIKE ? t : 0]);
+                for (int t = 0; t < MP; ++t) tf_blk_copy<B>(Es[ES ? q : 0][ES ? t : 0], Es[ES ? q + 1 : 0][ES ? t : 0]);
             }
         }
     };
     if (KNOWN) {
         const int np = DIR > 0 ? hdn : mI - hdn;     // this walk's half
-        for (int j = 0; j < np; ++j) pivot(j, TfInt<-1>());
+        for (int j = 0; j < np; ++j) {
+            if (j == 4) TF_STAMP_L1(a, DIR, SB + 4);
+            if (j == 5) TF_STAMP_L1(a, DIR, SB + 5);
+            pivot(j, TfInt<-1>());
+        }
+        TF_STAMP_L1(a, DIR, SB + 2);
         if (!ok) *a.status = 1;
         return;
     }
-    for (int j = 0; j < mI - MP; ++j) pivot(j, TfInt<-1>());
+    for (int j = 0; j < mI - MP; ++j) {
+        if (j == 4) TF_STAMP_L1(a, DIR, SB + 4);
+        if (j == 5) TF_STAMP_L1(a, DIR, SB + 5);
+        pivot(j, TfInt<-1>());
+    }
+    TF_STAMP_L1(a, DIR, SB + 2);
     pivot(mI - MP, TfInt<0>());
     if (MP > 1) pivot(mI - MP + 1, TfInt<(MP > 1 ? 1 : 0)>());
     static_assert(MP <= 2, "tip epilogue is written for MP <= 2");
-
-    // ---- tips: back-substitute the last MP pivots (local k = 0..MP-1 <-> local
-    // node mI-MP+k); unknowns beyond the interior are the separator ahead.
-    //   x_k = yb_k - sum_t Vb[k][t] s_behind[t] - sum_t Wb[k][t] s_ahead[t]
-    double yb[MP][B];
-    double Vb[SPIKE ? MP : 1][SPIKE ? MP : 1][B][B], Wb[SPIKE ? MP : 1][SPIKE ? MP : 1][B][B];
+    if (ROLE == 1) {
+        // the follower makes the V tips (tf_tips_out): it needs the U blocks that couple tip to tip.
+        // They go to the slot that is not the last pivot's (read before that pivot's barrier);
+        // the second barrier keeps this walk's staging (same LDS) behind the follower's last read.
+        double* hand = xch + (mI & 1) * (NX * 64);
 #pragma unroll
-    for (int k = MP - 1; k >= 0; --k) {
+        for (int k = 0; k + 1 < MP; ++k)
 #pragma unroll
-        for (int r = 0; r < B; ++r) yb[k][r] = yh[k][r];
-        if (SPIKE) {
+            for (int r = 0; r < B; ++r)
 #pragma unroll
-            for (int t = 0; t < MP; ++t) {
-                tf_blk_copy<B>(Vb[SPIKE ? k : 0][SPIKE ? t : 0], Eh[SPIKE ? k : 0][SPIKE ? t : 0]);
-                tf_blk_zero<B>(Wb[SPIKE ? k : 0][SPIKE ? t : 0]);
-            }
-        }
-#pragma unroll
-        for (int c = 1; c <= UW; ++c) {
-            const int kk = k + c;
-            if (kk >= 2 * MP) {
-                // beyond the separator ahead: no interior row reaches there, the
-                // (exchanged) pivot row holds an exact zero
-            } else if (kk < MP) {
-                tf_mv_sub<B>(yb[k], Uh[k][c - 1], yb[kk]);
-                if (SPIKE) {
-#pragma unroll
-                    for (int t = 0; t < MP; ++t) {
-                        tf_mm_sub<B>(Vb[SPIKE ? k : 0][SPIKE ? t : 0], Uh[k][c - 1], Vb[SPIKE ? kk : 0][SPIKE ? t : 0]);
-                        tf_mm_sub<B>(Wb[SPIKE ? k : 0][SPIKE ? t : 0], Uh[k][c - 1], Wb[SPIKE ? kk : 0][SPIKE ? t : 0]);
-                    }
-                }
-            } else if (SPIKE) {
-                const int t = kk - MP;                  // separator ahead, local position t
-#pragma unroll
-                for (int r = 0; r < B; ++r)
-#pragma unroll
-                    for (int cc = 0; cc < B; ++cc) Wb[SPIKE ? k : 0][SPIKE ? t : 0][r][cc] += Uh[k][c - 1][r][cc];
-            }
-        }
+                for (int c = 0; c < B; ++c) hand[((k * B + r) * B + c) * 64] = Uh[k][0][r][c];
+        TF_WG_BARRIER();
+        TF_WG_BARRIER();
     }
-
-    if (!KNOWN && a.fuse_asm) {
-        // the tips in natural orientation stay in registers: this walk's half of the separator's row
-        double yN[MP][B];
-        double VN[SPIKE ? MP : 1][SPIKE ? MP : 1][B][B], WN[SPIKE ? MP : 1][SPIKE ? MP : 1][B][B];
-#pragma unroll
-        for (int k = 0; k < MP; ++k) {
-            const int kn = DIR > 0 ? k : MP - 1 - k;
-#pragma unroll
-            for (int r = 0; r < B; ++r) yN[kn][r] = yb[k][r];
-            if (SPIKE) {
-#pragma unroll
-                for (int t = 0; t < MP; ++t) {
-                    const int tn = DIR > 0 ? t : MP - 1 - t;
-                    tf_blk_copy<B>(VN[SPIKE ? kn : 0][SPIKE ? tn : 0], DIR > 0 ? Vb[SPIKE ? k : 0][SPIKE ? t : 0] : Wb[SPIKE ? k : 0][SPIKE ? t : 0]);
-                    tf_blk_copy<B>(WN[SPIKE ? kn : 0][SPIKE ? tn : 0], DIR > 0 ? Wb[SPIKE ? k : 0][SPIKE ? t : 0] : Vb[SPIKE ? k : 0][SPIKE ? t : 0]);
-                }
-            }
-        }
-        tf_asm_side<Rows, DIR, SPIKE>(a, rows, pg, yN, VN, WN, asm_stage, asm_rec);
-        if (!ok) *a.status = 1;
-        return;
-    }
-    // ---- write in natural orientation
-    double* tips = DIR > 0 ? a.tips_dn : a.tips_up;
-    auto put = [&](int slot, double v) { tips[(int64_t)slot * L.Ptot + pg] = v; };
-#pragma unroll
-    for (int k = 0; k < MP; ++k) {
-        const int kn = DIR > 0 ? k : MP - 1 - k;        // natural tip index
-#pragma unroll
-        for (int r = 0; r < B; ++r) put(Tip::y(kn, r), yb[k][r]);
-        if (SPIKE) {
-#pragma unroll
-            for (int t = 0; t < MP; ++t) {
-                const int tn = DIR > 0 ? t : MP - 1 - t;
-#pragma unroll
-                for (int r = 0; r < B; ++r)
-#pragma unroll
-                    for (int c = 0; c < B; ++c) {
-                        // down: behind = above (V), ahead = below (W); up: the reverse
-                        const double vb = Vb[SPIKE ? k : 0][SPIKE ? t : 0][r][c];
-                        const double wb = Wb[SPIKE ? k : 0][SPIKE ? t : 0][r][c];
-                        put(Tip::V(kn, tn, r, c), DIR > 0 ? vb : wb);
-                        put(Tip::W(kn, tn, r, c), DIR > 0 ? wb : vb);
-                    }
-            }
-        }
-    }
+    tf_tips_out<Rows, DIR, SPIKE, ES, true, ROLE == 0>(a, rows, pg, Uh, yh, Eh, asm_stage, asm_rec);
+    TF_STAMP_L1(a, DIR, SB + 3);
     if (!ok) *a.status = 1;
+}
+
+// The right-hand sides of a split factorisation walk (ROLE 1 above publishes per pivot j: the
+// inverse of the pivot block and the MP blocks below it): the MP*B spike columns and the first
+// right-hand side of the step.  Same products in the same order as the one-wavefront form:
+// En = Dinv Es[0], Es[q] -= R[q][0] En (yn, y alike), the window slides.  Rows beyond the first
+// MP do not couple to the separator behind: only those are read from the Jacobian; the
+// right-hand side is requested one row ahead.
+template <class Rows, int DIR, bool STORE_U, bool STORE_Y>
+TF_DEVICE void tfk_rhs_follow_body(const TfLevelArgs& a, int pg, double* xch, double* asm_stage) {
+    constexpr int B = Rows::B, MP = Rows::MP, W = 2 * MP + 1;
+    constexpr int NX = (1 + MP) * B * B;
+    const TfLayout& L = a.L;
+    if (pg >= L.Ptot) return;
+    if (DIR > 0) TF_STAMP_T(a, 30, 64);
+    Rows rows(a, pg);
+    const int mI = rows.len - MP;
+    auto node = [&](int j) { return DIR > 0 ? j : mI - 1 - j; };
+    double Es[MP + 1][MP][B][B], Eh[MP][MP][B][B], y[MP + 1][B], yh[MP][B], ypre[B];
+    auto request = [&](int jl) {
+#pragma unroll
+        for (int r = 0; r < B; ++r)
+            ypre[r] = (a.rhs && jl < mI) ? tf_ldp(a.rhs, r, L.plane, tf_off8(L, pg, node(jl < mI ? jl : 0))) : 0.0;
+    };
+#pragma unroll
+    for (int q = 0; q <= MP; ++q) {
+#pragma unroll
+        for (int t = 0; t < MP; ++t) tf_blk_zero<B>(Es[q][t]);
+#pragma unroll
+        for (int r = 0; r < B; ++r) y[q][r] = 0.0;
+    }
+    request(0);
+#pragma unroll
+    for (int jl = 0; jl < MP; ++jl) {
+#pragma unroll
+        for (int r = 0; r < B; ++r) y[jl][r] = ypre[r];
+        request(jl + 1);
+        if (jl < mI) {
+            double row[W][B][B];
+            rows.load(node(jl), row);
+#pragma unroll
+            for (int d = -MP; d <= MP; ++d) {
+                const int t = MP + jl + d;                 // column jl + d < 0: separator behind
+                if (jl + d < 0 && t >= 0 && t < MP) tf_blk_copy<B>(Es[jl][t], row[(DIR > 0 ? d : -d) + MP]);
+            }
+        }
+    }
+    const int hdn = tf_twist_h<B, MP>(mI, a.twist);
+    auto step = [&](int j, auto hist_tag) {
+        constexpr int HIST = decltype(hist_tag)::value;
+        TF_WG_BARRIER();
+        const double* slot = xch + (j & 1) * (NX * 64);
+        double Dinv[B][B], En[MP][B][B], yn[B];
+#pragma unroll
+        for (int r = 0; r < B; ++r)
+#pragma unroll
+            for (int k = 0; k < B; ++k) Dinv[r][k] = slot[(r * B + k) * 64];
+        tf_mv<B>(yn, Dinv, y[0]);
+#pragma unroll
+        for (int t = 0; t < MP; ++t) tf_mm<B>(En[t], Dinv, Es[0][t]);
+        // row j + MP enters the window
+#pragma unroll
+        for (int r = 0; r < B; ++r) y[MP][r] = ypre[r];
+        request(j + MP + 1);
+        TF_PIN_REQUESTS();
+#pragma unroll
+        for (int q = 1; q <= MP; ++q) {
+            double M[B][B];
+#pragma unroll
+            for (int r = 0; r < B; ++r)
+#pragma unroll
+                for (int k = 0; k < B; ++k) M[r][k] = slot[((q * B + r) * B + k) * 64];
+            tf_mv_sub<B>(y[q], M, yn);
+#pragma unroll
+            for (int t = 0; t < MP; ++t) tf_mm_sub<B>(Es[q][t], M, En[t]);
+        }
+        // (a.respike: E and y of the first elimination are not kept)
+        const bool keep_u = a.respike ? (DIR > 0 ? j < hdn : j < mI - hdn) : DIR > 0;
+        if ((STORE_U || STORE_Y) && !a.respike) {
+            const unsigned off = tf_off8(L, pg, node(j));
+            if (STORE_U && keep_u) {
+#pragma unroll
+                for (int c = 0; c < MP; ++c)
+#pragma unroll
+                    for (int r = 0; r < B; ++r)
+#pragma unroll
+                        for (int k = 0; k < B; ++k) tf_stp(a.Et, (c * B + r) * B + k, L.plane, off, En[c][r][k]);
+            }
+            if (STORE_Y) {
+#pragma unroll
+                for (int r = 0; r < B; ++r) tf_stp(a.yt, r, L.plane, off, yn[r]);
+            }
+        }
+        if (HIST >= 0) {
+            constexpr int H = HIST >= 0 ? HIST : 0;
+#pragma unroll
+            for (int t = 0; t < MP; ++t) tf_blk_copy<B>(Eh[H][t], En[t]);
+#pragma unroll
+            for (int r = 0; r < B; ++r) yh[H][r] = yn[r];
+        }
+#pragma unroll
+        for (int q = 0; q < MP; ++q) {
+#pragma unroll
+            for (int t = 0; t < MP; ++t) tf_blk_copy<B>(Es[q][t], Es[q + 1][t]);
+#pragma unroll
+            for (int r = 0; r < B; ++r) y[q][r] = y[q + 1][r];
+        }
+#pragma unroll
+        for (int t = 0; t < MP; ++t) tf_blk_zero<B>(Es[MP][t]);
+    };
+    if (DIR > 0) TF_STAMP_T(a, 31, 64);
+    for (int j = 0; j < mI - MP; ++j) step(j, TfInt<-1>());
+    step(mI - MP, TfInt<0>());
+    if (MP > 1) step(mI - MP + 1, TfInt<(MP > 1 ? 1 : 0)>());
+    if (DIR > 0) TF_STAMP_T(a, 32, 64);
+    // the V and y tips are made here (tf_tips_out): the U blocks that couple tip to tip come from
+    // the band walk, in the slot that is not the last pivot's
+    double Uh[MP][1][B][B];
+#pragma unroll
+    for (int k = 0; k < MP; ++k) tf_blk_zero<B>(Uh[k][0]);
+    TF_WG_BARRIER();
+    const double* hand = xch + (mI & 1) * (NX * 64);
+#pragma unroll
+    for (int k = 0; k + 1 < MP; ++k)
+#pragma unroll
+        for (int r = 0; r < B; ++r)
+#pragma unroll
+            for (int c = 0; c < B; ++c) Uh[k][0][r][c] = hand[((k * B + r) * B + c) * 64];
+    TF_WG_BARRIER();
+    if (DIR > 0) TF_STAMP_T(a, 33, 64);
+    tf_tips_out<Rows, DIR, true, true, false, true>(a, rows, pg, Uh, yh, Eh, asm_stage, nullptr);
+    if (DIR > 0) TF_STAMP_T(a, 34, 64);
 }
 
 // ---- levels >= 2: block-tridiagonal chunks with stored factors --------------
@@ -1784,7 +2005,9 @@ TF_DEVICE void tfk_backsub_twist_body(const TfLevelArgs& a, int pg, int dir,
                 }
             }
         }
+        TF_STAMP_L1(a, 1 - 2 * dir, 6);
         if (!tf_dense_solve<NB>(S, g2)) *a.status = 1;
+        TF_STAMP_L1(a, 1 - 2 * dir, 7);
         // g2 = b; a = Tg - Tc b
 #pragma unroll
         for (int i = 0; i < NB; ++i)

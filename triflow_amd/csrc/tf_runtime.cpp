@@ -560,6 +560,12 @@ struct tf_solver {
         const int b = spec.mp * spec.nvar;
         return l1_fuse_asm && levels.size() > 1 && levels[1]->cr && (2 * b * b + 1) * 64 * 8 <= 40 * 1024;
     }
+    // one or two wavefronts per 64 chunks and direction: what the code object was built for
+    unsigned l1_factor_block_ = 0;
+    unsigned l1_factor_block() {
+        if (!l1_factor_block_) l1_factor_block_ = tfb::kernel_block(model->module, TFK_L1_FACTOR) == 128 ? 128 : 64;
+        return l1_factor_block_;
+    }
     // N < 2*mp + 1: dense factorisation, one thread per system (tfk_tiny_*)
     bool tiny = false;
     DevBuf tiny_lu;
@@ -695,7 +701,7 @@ struct tf_solver {
             TfLevelArgs a = level_args(l, rhs1, x1);
             if (!fused) a.rhs = nullptr;
             unsigned gx = cdiv(a.L.Ptot, 64);
-            if (l == 0) launch(fused ? TFK_L1_FACTOR_RHS : TFK_L1_FACTOR, gx, 2, 64, &a, sizeof(a));
+            if (l == 0) launch(fused ? TFK_L1_FACTOR_RHS : TFK_L1_FACTOR, gx, 2, l1_factor_block(), &a, sizeof(a));
             else if (levels[l]->cr) {
                 // one wavefront per chunk; leaves the next level's rows (and rhs) behind
                 a.cr_rhs = fused ? 1 : 0;
@@ -1706,9 +1712,12 @@ int tf_backward_error(tf_solver* s, double* omega, int32_t* refined) {
 int tf_debug_stamps(tf_solver* s, uint64_t* out, int32_t max_levels) {
     TF_API_BEGIN
     require(s && out, "null argument");
-    const size_t need = 64 * std::max<size_t>(s->levels.size(), 1);
+    // (regions beyond the solver's levels: per-workgroup begin / end times of the level-1 kernels,
+    // TF_WGTRACE in tf_entry_hip.h)
+    const size_t regions = std::max<size_t>(std::max<size_t>(s->levels.size(), 1), (size_t)std::max(max_levels, 0));
+    const size_t need = 64 * regions;
     if (s->stamp_buf.n < need) { s->drop_graphs(); s->stamp_buf.alloc(need, s->bytes); return 0; }
-    const size_t n = 64 * std::min<size_t>(s->levels.size(), (size_t)std::max(max_levels, 0));
+    const size_t n = 64 * std::min<size_t>(s->stamp_buf.n / 64, (size_t)std::max(max_levels, 0));
     tfb::d2h(out, s->stamp_buf.p, n * sizeof(uint64_t), s->stream);
     TF_API_END
 }
@@ -1729,6 +1738,14 @@ int tf_solver_counters(tf_solver* s, int64_t* factorisations, int64_t* checks, i
     if (factorisations) *factorisations = s->n_factor;
     if (checks) *checks = s->n_checks;
     if (replans) *replans = s->n_replans;
+    TF_API_END
+}
+
+int tf_solver_kernel_block(tf_solver* s, int32_t kernel, int32_t* block) {
+    TF_API_BEGIN
+    require(s && block, "null argument");
+    require(kernel >= 0 && kernel < TFK_COUNT, "no such kernel");
+    *block = (int32_t)tfb::kernel_block(s->model->module, kernel);
     TF_API_END
 }
 
