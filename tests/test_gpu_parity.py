@@ -528,6 +528,36 @@ def test_fused_level1_backsub_equals_two_launches(m1, monkeypatch):
     assert np.isfinite(out[0]).all() and np.array_equal(out[0], out[1])
 
 
+@pytest.mark.parametrize("cfg,sch,N,nsys,m1", [(3, "ROS2", 3001, 2, 32), (3, "ROS2", 2003, 1, 13),
+                                                 (5, "BDF2", 3001, 2, 32), (3, "RODASPR", 3001, 1, 32)])
+def test_state_update_inside_the_back_substitution(cfg, sch, N, nsys, m1, monkeypatch):
+    """The last solve of a fixed step of one or two stages leaves the new state instead of its
+    solution (tfk_l1_fwd2_backsub with TfLevelArgs::upd_*: base + (b0 k0 + b1 x), the operations of
+    the vector kernel in their order): the same bits as solve + tfk_vec, with a hook, with two
+    members, on chunks that are split in two and on one-sided ones; and the vector kernel is gone
+    from those steps (schemes with more stages keep it)."""
+    from triflow_amd.ensemble import Ensemble
+    name, fd, pars, dt, _ = corpus.config_inputs(cfg, N)
+    m = pc.device_model(name, HIP)
+    fields = {k: np.repeat(v[None, :], nsys, axis=0) * (1 + 0.01 * np.arange(nsys))[:, None]
+              for k, v in fd.items() if k != "x"}
+    hook = pc.DEVICE_HOOKS["cfg5"] if cfg == 5 else None
+    monkeypatch.setenv("TRIFLOW_L1_RESPIKE", "1")
+    out, vec_launches = [], []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("TRIFLOW_FUSE_UPDATE", fuse)
+        ens = Ensemble(m, fd["x"], fields, pars, bool(pars["periodic"]), scheme=sch, hook=hook, nstate=2, m1=m1, refine=0)
+        ens.solver.timing(True)
+        for _ in range(5):
+            ens.step(dt)
+        ens.sync()
+        out.append(ens.state().copy())
+        vec_launches.append(ens.solver.timing_report().get("tfk_vec", (0.0, 0))[1])
+        ens.close()
+    assert np.isfinite(out[0]).all() and np.array_equal(out[0], out[1])
+    assert vec_launches[1] == 5 and vec_launches[0] == (5 if sch == "RODASPR" else 0), vec_launches
+
+
 def test_fused_stage_rhs():
     pc.check_fused_stage_rhs(HIP)
 

@@ -219,6 +219,13 @@ struct TfLevelArgs {
     // level 1 below a cyclic-reduction level: the walks assemble the separator rows themselves
     // (tf_asm_side: no tips in memory, no tfk_l1_asm_* launch)
     int fuse_asm;
+    // tfk_l1_fwd2_backsub of the last solve of a time step: the new state leaves instead of x,
+    // upd_out = upd_base + upd_c0 x (upd_n == 1) or upd_base + (upd_c0 upd_k0 + upd_c1 x) (upd_n == 2)
+    double* upd_out;
+    const double* upd_base;
+    const double* upd_k0;
+    double upd_c0, upd_c1;
+    int upd_n;
     double* topAinv;               // [b][b] planes over systems (TfTopArgs::Ainv)
     double* topx;                  // [sys][b]
     // diagnostic builds (-DTF_STAMPS): one workgroup writes s_memtime stamps here (else NULL)

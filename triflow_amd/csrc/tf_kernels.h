@@ -52,9 +52,13 @@
 #define TF_COUNT(a, i) do { if ((a).stamps && (threadIdx.x & 63) == 0) atomicAdd(&(a).stamps[i], 1ull); } while (0)
 // ... and begin / end times (100 MHz) of every workgroup of a level-1 kernel: region k of 2048
 // entries behind the 8 level regions (tools/gpu_wgtrace.py asks for that many)
+// (level-1 walks: the down walk of the middle workgroup; slots 0.. re-elimination, 10.. factorisation,
+// 20.. first solve walk)
+#define TF_STAMP_L1(a, dir, i) do { if ((dir) > 0 && blockIdx.y == 0) TF_STAMP(a, i); } while (0)
 #define TF_WGTRACE(a, k, which) do { if ((a).stamps && threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < 1024) \
         (a).stamps[512 + 2048 * (k) + 2 * (blockIdx.y * gridDim.x + blockIdx.x) + (which)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
+#define TF_STAMP_L1(a, dir, i) do {} while (0)
 #define TF_WGTRACE(a, k, which) do {} while (0)
 #define TF_STAMP(a, i) do {} while (0)
 #define TF_STAMP_T(a, i, tid) do {} while (0)
@@ -62,9 +66,6 @@
 #define TF_COUNT(a, i) do {} while (0)
 #endif
 
-// (level-1 walks: the down walk of the middle workgroup; slots 0.. re-elimination, 10.. factorisation,
-// 20.. first solve walk)
-#define TF_STAMP_L1(a, dir, i) do { if ((dir) > 0 && blockIdx.y == 0) TF_STAMP(a, i); } while (0)
 
 // workgroup barrier of the kernels whose wavefronts work together (the emulation runs the
 // one-wavefront forms of those: nothing to wait for)
@@ -1907,30 +1908,59 @@ TF_DEVICE void tfk_backsub_twist_body(const TfLevelArgs& a, int pg, int dir,
 #pragma unroll
                 for (int k = 0; k < B; ++k) U[c][r][k] = tf_ldp(a.Ut, (c * B + r) * B + k, L.plane, off);
     };
-    auto emit = [&](int nd, const double (&x)[B]) {     // the solution at node `nd` of the chunk
-        const int64_t s = tf_idx(L, pg, nd);
+    // a.upd_n (the launch that holds the re-elimination, YLDS): the solve is the last one of a time
+    // step and what leaves is the new state, base + c0 x (one term) or base + (c0 k0 + c1 x) -- the
+    // operations of tfk_vec in their order -- instead of x.  The other operands of a node are
+    // requested ahead of their use like its factors.
+    struct Upd { double b[B], k[B]; };
+    const bool upd = YLDS && a.upd_n > 0;
+    auto upd_load = [&](int nd, Upd& u) {
+        if (upd) {
+            const unsigned off = tf_off8(L, pg, nd);
 #pragma unroll
-        for (int r = 0; r < B; ++r) a.x[(int64_t)r * L.plane + s] = x[r];
+            for (int r = 0; r < B; ++r) {
+                u.b[r] = tf_ldp(a.upd_base, r, L.plane, off);
+                u.k[r] = a.upd_n > 1 ? tf_ldp(a.upd_k0, r, L.plane, off) : 0.0;
+            }
+        }
     };
-    if (hu == 0 || dir == 0) {
+    auto emit = [&](int nd, const double (&x)[B], const Upd& u) {     // the solution at node `nd` of the chunk
+        const int64_t s = tf_idx(L, pg, nd);
+        if (upd) {
+#pragma unroll
+            for (int r = 0; r < B; ++r) {
+                double acc;
+                if (a.upd_n > 1) { acc = a.upd_c0 * u.k[r]; acc = acc + a.upd_c1 * x[r]; }
+                else acc = a.upd_c0 * x[r];
+                a.upd_out[(int64_t)r * L.plane + s] = u.b[r] + acc;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < B; ++r) a.x[(int64_t)r * L.plane + s] = x[r];
+        }
+    };
+    // the separator and the nodes next to the middle leave at the end (their other operands are
+    // requested once the middle system is solved, which needs the registers)
+    double xsep[MP][B], xmid[MP][B];
+    const bool own_sep = hu == 0 || dir == 0;
+    if (own_sep) {
         // the chunk's own separator: solved by the next level
         int p2, i2;
         tf_locate(a.Lnext, p, p2, i2);
         const int64_t s2 = tf_idx(a.Lnext, e * a.Lnext.P + p2, i2);
 #pragma unroll
         for (int t = 0; t < MP; ++t) {
-            const int64_t s = tf_idx(L, pg, mI + t);
 #pragma unroll
             for (int r = 0; r < B; ++r) {
                 const double v = a.xnext[tf_next_x(a, e, p, s2, t * B + r, MP * B)];
                 xn[t][r] = v;
-                a.x[(int64_t)r * L.plane + s] = v;
+                xsep[t][r] = v;
             }
         }
     }
     // the factors of the first streamed nodes are requested before the middle system is solved
-    struct Node { double y[B]; double U[MP][B][B]; };
-    auto load = [&](int j, Node& n) { ldU(nat(j), n.U, n.y); };
+    struct Node { double y[B]; double U[MP][B][B]; Upd u; };
+    auto load = [&](int j, Node& n) { ldU(nat(j), n.U, n.y); upd_load(nat(j), n.u); };
     constexpr int D = TF_BACKSUB_DEPTH;
     Node ring[D];
 #pragma unroll
@@ -2015,23 +2045,23 @@ TF_DEVICE void tfk_backsub_twist_body(const TfLevelArgs& a, int pg, int dir,
             for (int c = 0; c < NB; ++c) Tg[i] = tf_fma(-Tc[i][c], g2[c], Tg[i]);
         if (dir == 0) {
 #pragma unroll
-            for (int k = 0; k < MP; ++k) {
-                double xk[B];
+            for (int k = 0; k < MP; ++k)
 #pragma unroll
-                for (int r = 0; r < B; ++r) { xk[r] = Tg[k * B + r]; xn[k][r] = Tg[k * B + r]; }
-                emit(h - MP + k, xk);
-            }
+                for (int r = 0; r < B; ++r) { xmid[k][r] = Tg[k * B + r]; xn[k][r] = Tg[k * B + r]; }
             // (ahead of node h-MP-1: h-MP (a_0), h-MP+1 (a_1), ...)
         } else {
 #pragma unroll
-            for (int k = 0; k < MP; ++k) {
-                double xk[B];
+            for (int k = 0; k < MP; ++k)
 #pragma unroll
-                for (int r = 0; r < B; ++r) { xk[r] = g2[k * B + r]; xn[MP - 1 - k][r] = g2[k * B + r]; }
-                emit(h + k, xk);
-            }
+                for (int r = 0; r < B; ++r) { xmid[k][r] = g2[k * B + r]; xn[MP - 1 - k][r] = g2[k * B + r]; }
             // (ahead of node h+MP, walking up: h+MP-1 (b_{MP-1}), ...)
         }
+    }
+    Upd usep[MP], umid[MP];
+#pragma unroll
+    for (int t = 0; t < MP; ++t) {
+        if (own_sep) upd_load(mI + t, usep[t]);
+        if (hu != 0) upd_load(dir == 0 ? h - MP + t : h + t, umid[t]);
     }
     for (int j0 = jstart; j0 >= 0; j0 -= D) {
 #pragma unroll
@@ -2050,9 +2080,14 @@ TF_DEVICE void tfk_backsub_twist_body(const TfLevelArgs& a, int pg, int dir,
                 for (int r = 0; r < B; ++r) xn[c][r] = xn[c - 1][r];
 #pragma unroll
             for (int r = 0; r < B; ++r) xn[0][r] = x[r];
-            emit(nat(j), x);
+            emit(nat(j), x, cur.u);
             if (j - D >= 0) load(j - D, ring[d]);
         }
+    }
+#pragma unroll
+    for (int t = 0; t < MP; ++t) {
+        if (own_sep) emit(mI + t, xsep[t], usep[t]);
+        if (hu != 0) emit(dir == 0 ? h - MP + t : h + t, xmid[t], umid[t]);
     }
 }
 

@@ -745,6 +745,25 @@ struct tf_solver {
         have_factor = true;                          // (the sweep of this step reset it)
         solve(rhs1, x1);
     }
+    // The last solve of a time step may leave the new state instead of its solution (TfLevelArgs
+    // upd_*: tfk_l1_fwd2_backsub adds base and the earlier stages while it back-substitutes -- no
+    // vector kernel, no write and re-read of the last stage).  A step function asks for it right
+    // before that solve; it happens when the launch in question is the one that can do it and nobody
+    // needs the solution itself afterwards (a checked or refined solve does); otherwise the step
+    // function runs the vector kernel as before.
+    struct Update { double* out; const double* base; const double* k0; double c0, c1; int n; };
+    Update upd_req{};
+    bool upd_req_on = false, upd_done = false;
+    bool upd_fuse = true;          // (TRIFLOW_FUSE_UPDATE=0: A/B runs, tests)
+    void request_update(double* out, const double* base, const double* k0, double c0, double c1, int n) {
+        upd_req = Update{out, base, k0, c0, c1, n};
+        upd_req_on = upd_fuse;
+        upd_done = false;
+    }
+    bool take_update_done() { const bool d = upd_done; upd_done = false; upd_req_on = false; return d; }
+    bool update_allowed() const {
+        return !delegated && !tiny && refine <= 0 && (refine != -1 || (fact_checked && sweeps_needed == 0));
+    }
     // skip: that many of the last levels have been back-substituted already (1: the last level
     // inside its forward / factor kernel -- a cyclic-reduction level that folds the top block
     // in; 2: the two last levels by tfk_cr_tail)
@@ -754,8 +773,15 @@ struct tf_solver {
             if (l == 0) {
                 // (twisted: grid.y = 2, the down and the up half of every chunk, tf_twist_h)
                 const unsigned gy = a.twist ? 2u : 1u;
+                const bool take = upd_req_on && update_allowed();
+                upd_req_on = false;                                   // (one solve only: not its refinement sweeps)
                 if (const unsigned lds = l1_twist_lds(a)) {
                     // both in one launch, y in LDS
+                    if (take) {
+                        a.upd_out = upd_req.out; a.upd_base = upd_req.base; a.upd_k0 = upd_req.k0;
+                        a.upd_c0 = upd_req.c0; a.upd_c1 = upd_req.c1; a.upd_n = upd_req.n;
+                        upd_done = true;
+                    }
                     launch(TFK_L1_FWD2_BACKSUB, cdiv(a.L.Ptot, 64), 1, 128, &a, sizeof(a), lds);
                     continue;
                 }
@@ -1054,6 +1080,7 @@ tf_solver* make_solver(tf_model* model, int64_t N, int32_t nsys, int32_t periodi
     if (const char* v = getenv("TRIFLOW_L1_FUSE_BACKSUB")) s->l1_fuse_backsub = atoi(v) != 0;
     if (const char* v = getenv("TRIFLOW_TWO_FACTORS")) s->two_slots = atoi(v) != 0;
     if (const char* v = getenv("TRIFLOW_L1_FUSE_ASM")) s->l1_fuse_asm = atoi(v) != 0;
+    if (const char* v = getenv("TRIFLOW_FUSE_UPDATE")) s->upd_fuse = atoi(v) != 0;
     s->l1_respike = TF_RESPIKE_MODEL(sp.mp, sp.nvar) && (int64_t)N * nsys >= TF_RESPIKE_MIN_NODES;
     if (const char* v = getenv("TRIFLOW_L1_TWIST")) s->l1_twist = atoi(v) != 0 ? 1 : 0;
     if (const char* v = getenv("TRIFLOW_L1_RESPIKE"))                                   // A/B runs, tests
@@ -1500,11 +1527,14 @@ void step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns, con
             for (int j = 0; j < i; ++j) { ks[j] = s->K[j].p; cs[j] = alpha[i * ns + j]; gs[j] = gamma[i * ns + j]; }
             s->stage_rhs(Uin, i, ks, cs, gs, dt, s->Wrhs.p, i == 1 ? s->F.p : nullptr);
         }
+        // the last stage of a fixed step of one or two stages: the new state leaves with the solve
+        if (i == ns - 1 && ns <= 2 && !(b_pred && want_err))
+            s->request_update(U, Uin, ns == 2 ? s->K[0].p : nullptr, b[0], ns == 2 ? b[1] : 0.0, ns);
         if (i == 0) s->factor_step(gamma[0] * dt, s->F.p, s->K[0].p); // factorise + first stage
         else s->solve(s->Wrhs.p, s->K[i].p);
     }
     for (int j = 0; j < ns; ++j) { ks[j] = s->K[j].p; cs[j] = b[j]; }
-    s->vec(TF_VEC_SUM, U, Uin, ns, ks, cs);                        // U + sum_i b_i k_i
+    if (!s->take_update_done()) s->vec(TF_VEC_SUM, U, Uin, ns, ks, cs);   // U + sum_i b_i k_i
     if (b_pred && want_err) {
         s->zero(s->red.p, sizeof(double));
         for (int j = 0; j < ns; ++j) cs[j] = b_pred[j];
@@ -1650,9 +1680,10 @@ void step_bdf2(tf_solver* s, int32_t src, int32_t dst, double dt, tf_solver::Bdf
     s->sweep_bdf2(Uin, two_step, 1.0 / 3.0, two_step ? (2.0 / 3.0) * dt : dt, s->Wrhs.p, h.Uprev.p);
     h.have_prev = true;
     h.dt_prev = dt;
+    s->request_update(U, Uin, nullptr, 1.0, 0.0, 1);               // (1.0 * x == x: the sum of TF_VEC_ADD)
     s->factor_step(two_step ? (2.0 / 3.0) * dt : dt, s->Wrhs.p, s->Wdel.p);
     const double* ys[2] = {Uin, s->Wdel.p};
-    s->vec(TF_VEC_ADD, U, nullptr, 2, ys, nullptr);
+    if (!s->take_update_done()) s->vec(TF_VEC_ADD, U, nullptr, 2, ys, nullptr);
     s->apply_dirichlet(U, true);
 }
 }  // namespace
