@@ -245,6 +245,70 @@ def check_respike(backend):
         assert np.isfinite(out[0]).all() and err <= 1e-10, (cfg, sch, err)
 
 
+def check_hook_input_in_place(backend):
+    """A step with a Dirichlet hook starts from a copy of the state with the hook applied
+    (schemes.py:144-145, 548-549).  The device skips the copy when the source slot is what an
+    earlier step left with the hook applied at the same time and nothing has written it since
+    (tf_solver::slot_hook): the same states as with the copy (TRIFLOW_HOOK_IN_PLACE=0) -- constant and
+    time-dependent boundary values, a state uploaded in between (the next step copies again), a
+    restart, and the scheme objects driven from Python."""
+    import os
+    from triflow_amd.ensemble import Ensemble
+
+    def with_env(value, fn):
+        os.environ["TRIFLOW_HOOK_IN_PLACE"] = value
+        try:
+            return fn()
+        finally:
+            del os.environ["TRIFLOW_HOOK_IN_PLACE"]
+
+    moving = DirichletHook(A={0: lambda t: 1.0 + 0.5 * t, -1: 1.0})
+    for cfg, sch, hook, N in ((5, "BDF2", DEVICE_HOOKS["cfg5"], 1203), (1, "Theta", DEVICE_HOOKS["cfg1"], 200),
+                              (5, "ROS2", DEVICE_HOOKS["cfg5"], 803), (5, "BDF2", moving, 611)):
+        name, fd, pars, dt, _ = corpus.config_inputs(cfg, N)
+        m = device_model(name, backend)
+        fields = {k: v[None, :] for k, v in fd.items() if k != "x"}
+        out = []
+        for flag in ("1", "0"):
+            def run():
+                ens = Ensemble(m, fd["x"], fields, pars, bool(pars["periodic"]), scheme=sch, hook=hook, nstate=3)
+                states = []
+                for _ in range(4):
+                    ens.step(dt)
+                ens.sync()
+                states.append(ens.state().copy())
+                # a state from outside: the slot no longer holds what a step left
+                ens.solver.set_state(ens.cur, states[0] * 1.001)
+                for _ in range(3):
+                    ens.step(dt)
+                ens.sync()
+                states.append(ens.state().copy())
+                ens.restart()
+                for _ in range(3):
+                    ens.step(dt)
+                ens.sync()
+                states.append(ens.state().copy())
+                ens.close()
+                return states
+            out.append(with_env(flag, run))
+        for a, b in zip(*out):
+            assert np.isfinite(a).all() and np.array_equal(a, b), (cfg, sch)
+    # the scheme objects (fields in, fields out): five steps with the hook, against the copy form
+    for flag_states in [[]]:
+        name, fd, pars, dt, _ = corpus.config_inputs(5, 403)
+        for flag in ("1", "0"):
+            def run():
+                m = device_model(name, backend)
+                scheme = schemes.BDF2(m)
+                fields = m.fields_template(**fd)
+                t = 0.0
+                for _ in range(5):
+                    t, fields = scheme(t, fields, dt, pars, hook=DEVICE_HOOKS["cfg5"])
+                return np.array(fields.uflat)
+            flag_states.append(with_env(flag, run))
+        assert np.array_equal(flag_states[0], flag_states[1])
+
+
 # ---------------------------------------------------------------- seam #2: schemes
 DEVICE_SCHEMES = {
     "Theta1": lambda m: schemes.Theta(m, theta=1),

@@ -501,6 +501,10 @@ def test_ensemble_restart():
     pc.check_ensemble_restart(HIP)
 
 
+def test_hook_input_in_place():
+    pc.check_hook_input_in_place(HIP)
+
+
 def test_respike():
     pc.check_respike(HIP)
 

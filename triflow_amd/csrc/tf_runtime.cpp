@@ -617,8 +617,25 @@ struct tf_solver {
 
     // State a step starts from: the reference copies the fields and applies the hook to
     // the copy (schemes.py:144-145, 548-549); without a hook the source slot is read in place.
+    // A slot that a step of this solver left with the hook applied at t + dt, and that nothing
+    // has written since, already holds what the copy would hold after the hook at the same t: it is
+    // read in place as well (`slot_hook`: the Dirichlet values a slot's contents satisfy, compared
+    // with the ones about to be applied).  Config 5: 160 MB less copied per step.
+    std::vector<std::vector<double>> slot_hook;
+    std::vector<double> dir_h, dir_post_h;         // host mirrors of dir_val / dir_val_post
+    bool hook_in_place = true;                     // (TRIFLOW_HOOK_IN_PLACE=0: A/B runs, tests)
+    void slot_written(int slot) { if (slot >= 0 && (size_t)slot < slot_hook.size()) slot_hook[slot].clear(); }
+    void mark_hooked(int slot) {
+        if (slot < 0) return;
+        if ((size_t)slot >= slot_hook.size()) slot_hook.resize((size_t)slot + 1);
+        slot_hook[slot] = dir_post_h;
+    }
+    bool input_is_hooked(int src) const {
+        return hook_in_place && ndir > 0 && src >= 0 && (size_t)src < slot_hook.size() &&
+               !slot_hook[src].empty() && slot_hook[src] == dir_h;
+    }
     const double* stage_input(int src, double* U) {
-        if (ndir == 0) return st(src);
+        if (ndir == 0 || input_is_hooked(src)) return st(src);
         copy(U, st(src), (size_t)vecn() * sizeof(double));
         apply_dirichlet(U);
         return U;
@@ -1081,6 +1098,7 @@ tf_solver* make_solver(tf_model* model, int64_t N, int32_t nsys, int32_t periodi
     if (const char* v = getenv("TRIFLOW_TWO_FACTORS")) s->two_slots = atoi(v) != 0;
     if (const char* v = getenv("TRIFLOW_L1_FUSE_ASM")) s->l1_fuse_asm = atoi(v) != 0;
     if (const char* v = getenv("TRIFLOW_FUSE_UPDATE")) s->upd_fuse = atoi(v) != 0;
+    if (const char* v = getenv("TRIFLOW_HOOK_IN_PLACE")) s->hook_in_place = atoi(v) != 0;
     s->l1_respike = TF_RESPIKE_MODEL(sp.mp, sp.nvar) && (int64_t)N * nsys >= TF_RESPIKE_MIN_NODES;
     if (const char* v = getenv("TRIFLOW_L1_TWIST")) s->l1_twist = atoi(v) != 0 ? 1 : 0;
     if (const char* v = getenv("TRIFLOW_L1_RESPIKE"))                                   // A/B runs, tests
@@ -1214,6 +1232,7 @@ int tf_set_state(tf_solver* s, int32_t slot, int32_t first, int32_t nv, const do
     TF_API_BEGIN
     require(s && host, "null argument");
     require(first >= 0 && nv >= 1 && first + nv <= s->spec.nvar, "tf_set_state: variable range");
+    s->slot_written(slot);
     s->upload_planes(host, s->st(slot) + (int64_t)first * s->plane(), nv);
     TF_API_END
 }
@@ -1228,6 +1247,7 @@ int tf_get_state(tf_solver* s, int32_t slot, int32_t first, int32_t nv, double* 
 int tf_set_state_flat(tf_solver* s, int32_t slot, const double* uflat) {
     TF_API_BEGIN
     require(s && uflat, "null argument");
+    s->slot_written(slot);
     s->upload_aos(uflat, s->st(slot), s->spec.nvar);
     TF_API_END
 }
@@ -1241,7 +1261,10 @@ int tf_get_state_flat(tf_solver* s, int32_t slot, double* uflat) {
 int tf_copy_state(tf_solver* s, int32_t src, int32_t dst) {
     TF_API_BEGIN
     require(s, "null solver");
-    if (src != dst) tfb::d2d(s->st(dst), s->st(src), (size_t)s->vecn() * sizeof(double), s->stream);
+    if (src != dst) {
+        tfb::d2d(s->st(dst), s->st(src), (size_t)s->vecn() * sizeof(double), s->stream);
+        s->slot_written(dst);
+    }
     TF_API_END
 }
 int tf_set_helpers(tf_solver* s, int32_t first, int32_t count, const double* host) {
@@ -1317,7 +1340,10 @@ int tf_set_dirichlet(tf_solver* s, int32_t n, const int32_t* var, const int64_t*
         tfb::h2d(s->dir_val.p, value, sizeof(double) * n, s->stream);
         tfb::h2d(s->dir_val_post.p, value, sizeof(double) * n, s->stream);
         s->ndir = n;
+        s->dir_h.assign(value, value + n);
+        s->dir_post_h = s->dir_h;
     }
+    s->slot_hook.clear();
     TF_API_END
 }
 
@@ -1328,6 +1354,7 @@ int tf_poke(tf_solver* s, int32_t slot, int32_t n, const int32_t* var, const int
     require(s, "null solver");
     require(n >= 0, "tf_poke: n");
     if (n == 0) return 0;
+    s->slot_written(slot);
     require(var && node && value, "tf_poke: null arrays");
     std::vector<int> nodes(n);
     for (int i = 0; i < n; ++i) {
@@ -1395,8 +1422,8 @@ int tf_set_dirichlet_values(tf_solver* s, const double* before, const double* af
     TF_API_BEGIN
     require(s, "null solver");
     if (s->ndir > 0) {
-        if (before) tfb::h2d(s->dir_val.p, before, sizeof(double) * s->ndir, s->stream);
-        if (after) tfb::h2d(s->dir_val_post.p, after, sizeof(double) * s->ndir, s->stream);
+        if (before) { tfb::h2d(s->dir_val.p, before, sizeof(double) * s->ndir, s->stream); s->dir_h.assign(before, before + s->ndir); }
+        if (after) { tfb::h2d(s->dir_val_post.p, after, sizeof(double) * s->ndir, s->stream); s->dir_post_h.assign(after, after + s->ndir); }
     }
     TF_API_END
 }
@@ -1500,10 +1527,12 @@ namespace {
 void step_theta(tf_solver* s, int32_t src, int32_t dst, double dt, double theta) {
     require(src != dst, "tf_step_theta: src and dst slots must differ");
     double* U = s->st(dst);
+    s->slot_written(dst);
     const double* Uin = s->stage_input(src, U);                    // copy + hook only when there is a hook
     s->sweep_theta(Uin, dt, theta, s->Wrhs.p);                     // F, J, dt*(F - (theta*J)@U) + U
     s->factor_step(theta * dt, s->Wrhs.p, U);
     s->apply_dirichlet(U, true);
+    s->mark_hooked(dst);
 }
 
 // Rosenbrock-Wanner fixed step, reference schemes.py:142-174.  With b_pred the maximum of
@@ -1513,6 +1542,7 @@ void step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns, con
     require(ns >= 1 && ns <= 6, "tf_step_row: 1 <= s <= 6");
     require(src != dst, "tf_step_row: src and dst slots must differ");
     double* U = s->st(dst);
+    s->slot_written(dst);
     const double* Uin = s->stage_input(src, U);
     s->sweep(Uin, true, 0, nullptr, nullptr, dt);   // J(U) and dt*F(U): right-hand side of stage 0
     const double* ks[TF_MAX_TERMS];
@@ -1540,7 +1570,7 @@ void step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns, con
         for (int j = 0; j < ns; ++j) cs[j] = b_pred[j];
         s->vec(TF_VEC_MAXABS, nullptr, U, ns, ks, cs);             // ||U - (U + sum b_pred k)||_inf
     }
-    if (hook_after) s->apply_dirichlet(U, true);
+    if (hook_after) { s->apply_dirichlet(U, true); s->mark_hooked(dst); }
 }
 
 // per system and variable ||state[a] - state[b]||_ord (ord 2 / 0 = max), out[nsys][nvar]
@@ -1585,7 +1615,7 @@ int tf_step_theta(tf_solver* s, int32_t src, int32_t dst, double dt, double thet
     TF_API_BEGIN
     require(s, "null solver");
     const std::string key = "T|" + std::to_string(src) + ">" + std::to_string(dst) + "|" + bits_of(dt) + "|" +
-        bits_of(theta) + "|" + std::to_string(s->ndir) + "|" + std::to_string(s->sweeps_for(theta * dt)) + "|" + std::to_string(s->refine) +
+        bits_of(theta) + "|" + std::to_string(s->ndir) + (s->input_is_hooked(src) ? "h" : "c") + "|" + std::to_string(s->sweeps_for(theta * dt)) + "|" + std::to_string(s->refine) +
         s->slot_key(theta * dt);      // (a step that reuses a factorisation is another string of launches, on its buffers)
     s->prepare_step(theta * dt);
     s->run_graphed(key, s->step_graphable(theta * dt), [&] { step_theta(s, src, dst, dt, theta); });
@@ -1599,7 +1629,7 @@ int tf_step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns,
     require(s && alpha && gamma && b, "null argument");
     require(ns >= 1 && ns <= 6, "tf_step_row: 1 <= s <= 6");
     std::string key = "R|" + std::to_string(src) + ">" + std::to_string(dst) + "|" + bits_of(dt) + "|" +
-        std::to_string(ns) + "|" + std::to_string(hook_after) + "|" + std::to_string(s->ndir) + "|" +
+        std::to_string(ns) + "|" + std::to_string(hook_after) + "|" + std::to_string(s->ndir) + (s->input_is_hooked(src) ? "h" : "c") + "|" +
         std::to_string(s->sweeps_for(gamma[0] * dt)) + "|" + std::to_string(s->refine) + "|" + (b_pred && err_out ? "e" : "-") +
         (s->will_monitor(gamma[0] * dt) ? "m" : "-") + s->slot_key(gamma[0] * dt);
     s->prepare_step(gamma[0] * dt);
@@ -1673,6 +1703,7 @@ void step_bdf2(tf_solver* s, int32_t src, int32_t dst, double dt, tf_solver::Bdf
     require(src != dst, "tf_step_bdf2: src and dst slots must differ");
     if (h.Uprev.n == 0) h.Uprev.alloc((size_t)s->vecn(), s->bytes);     // history buffers are made on first use
     double* U = s->st(dst);
+    s->slot_written(dst);
     const double* Uin = s->stage_input(src, U);
     const bool two_step = continuing && h.have_prev &&
         std::fabs(h.dt_prev - dt) <= 1e-12 * std::fabs(dt);
@@ -1685,6 +1716,7 @@ void step_bdf2(tf_solver* s, int32_t src, int32_t dst, double dt, tf_solver::Bdf
     const double* ys[2] = {Uin, s->Wdel.p};
     if (!s->take_update_done()) s->vec(TF_VEC_ADD, U, nullptr, 2, ys, nullptr);
     s->apply_dirichlet(U, true);
+    s->mark_hooked(dst);
 }
 }  // namespace
 extern "C" {
