@@ -284,7 +284,10 @@ struct TfTopArgs {                 // final 1-node system per ensemble member
 // (profiles/r03_ab_runs.txt, r3o).  Not for scalar models (rows are exchanged there).  The code
 // object says which form it holds: the launch bound of tfk_l1_factor is 128 or 64
 // (tfb::kernel_block).
-#define TF_L1_SPLIT_MODEL(mp, nvar) ((nvar) >= 2 && 2 * (1 + (mp)) * (nvar) * (nvar) * 64 * 8 <= 40 * 1024)
+#ifndef TF_L1_SPLIT_LDS
+#define TF_L1_SPLIT_LDS (40 * 1024)
+#endif
+#define TF_L1_SPLIT_MODEL(mp, nvar) ((nvar) >= 2 && 2 * (1 + (mp)) * (nvar) * (nvar) * 64 * 8 <= TF_L1_SPLIT_LDS)
 
 // nodes per thread of tfk_sweep_f_stage_rhs (the other sweeps: TF_SEG of the code object, 4 or 8).
 // Two register windows per variable make its ghost rows twice as expensive: 8 nodes per thread
