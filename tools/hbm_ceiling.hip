@@ -61,6 +61,33 @@ __global__ void __launch_bounds__(64) chunk_walk(const double* __restrict__ in, 
         for (int k = 0; k < NR; ++k) cur[k] = nxt[k];
     }
 }
+// the same walk over a node-major layout inside a group of 64 chunks, [group][row][plane][lane]:
+// a wavefront's stream is contiguous (NR * 512 bytes per row, rows back to back)
+template <int NR, int NW>
+__global__ void __launch_bounds__(64) chunk_walk_nm(const double* __restrict__ in, double* __restrict__ out, long n, int stride, int rows) {
+    const long col = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= stride) return;
+    const long g = blockIdx.x, lane = threadIdx.x;
+    auto at = [&](int r, int k, int npl) { return ((g * rows + r) * npl + k) * 64 + lane; };
+    double cur[NR], nxt[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) cur[k] = in[at(rows - 1, k, NR)];
+    double carry = 0.0;
+    for (int r = rows - 1; r >= 0; --r) {
+        if (r > 0) {
+#pragma unroll
+            for (int k = 0; k < NR; ++k) nxt[k] = in[at(r - 1, k, NR)];
+        }
+        double acc = carry;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) acc = fma(cur[k], 1.0000001, acc);
+        carry = acc * 0.5;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) out[at(r, k, NW)] = acc + k;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) cur[k] = nxt[k];
+    }
+}
 __global__ void __launch_bounds__(256) fill2(double2* __restrict__ out, long n2) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x)
         out[i] = make_double2(1.0, 2.0);
@@ -138,6 +165,19 @@ int main() {
             report("chunk_walk r39 w3, cold inputs (4 sets)", 42.0 * n * 8, ms);
             ms = time_ms([&] { chunk_walk<22, 3><<<g2, 64>>>(big + (long)(turn++ % 4) * 40 * n, out, n, stride, rows); }, 32);
             report("chunk_walk r22 w3, cold inputs (4 sets)", 25.0 * n * 8, ms);
+        }
+        for (int rows : {32}) {
+            const int stride = (int)(n / rows) / 64 * 64;          // whole groups
+            const int g2 = stride / 64;
+            ms = time_ms([&] { chunk_walk_nm<39, 3><<<g2, 64>>>(big + (long)(turn++ % 4) * 40 * n, out, n, stride, rows); }, 32);
+            report("chunk_walk r39 w3, node-major groups, cold inputs", 42.0 * stride * rows * 8, ms);
+            ms = time_ms([&] { chunk_walk_nm<22, 3><<<g2, 64>>>(big + (long)(turn++ % 4) * 40 * n, out, n, stride, rows); }, 32);
+            report("chunk_walk r22 w3, node-major groups, cold inputs", 25.0 * stride * rows * 8, ms);
+            ms = time_ms([&] { chunk_walk_nm<10, 18><<<g2, 64>>>(big + (long)(turn++ % 4) * 40 * n, big + (long)((turn + 1) % 4) * 40 * n, n, stride, rows); }, 32);
+            report("chunk_walk r10 w18 (factorisation mix), node-major, cold", 28.0 * stride * rows * 8, ms);
+            const int stride0 = (int)(n / rows), g0 = (stride0 + 63) / 64;
+            ms = time_ms([&] { chunk_walk<10, 18><<<g0, 64>>>(big + (long)(turn++ % 4) * 40 * n, big + (long)((turn + 1) % 4) * 40 * n, n, stride0, rows); }, 32);
+            report("chunk_walk r10 w18 (factorisation mix), planes, cold", 28.0 * n * 8, ms);
         }
         const int blk2 = 256; const int gridp = (int)((n + blk2 - 1) / blk2);
         ms = time_ms([&] { planes<25, 1><<<gridp, blk2>>>(big + (long)(turn++ % 4) * 40 * n, out, n); }, 32);
