@@ -37,18 +37,22 @@ def build(model, parvec_mask=0, opt="-O1"):
     os.makedirs(BUILD, exist_ok=True)
     so = os.path.join(BUILD, "emu_%s.so" % tag)
     if not os.path.exists(so):
+        # (pytest-xdist workers build the same library at the same time: every file under its own name
+        # until it is complete)
         hdr = os.path.join(BUILD, "model_%s.h" % tag)
-        with open(hdr, "w") as f:
+        with open(hdr + ".%d.tmp" % os.getpid(), "w") as f:
             f.write(src)
+        os.replace(hdr + ".%d.tmp" % os.getpid(), hdr)
+        tmp = so + ".%d.tmp" % os.getpid()
         cmd = ["g++", "-std=c++17", *opt.split(), "-g0", "-shared", "-fPIC", "-ffp-contract=off",
                "-fno-fast-math", "-I", CSRC, "-I", os.path.join(ROOT, "include"),
                '-DTF_EMU_MODEL_HEADER="%s"' % hdr,
                os.path.join(CSRC, "tf_runtime.cpp"), os.path.join(HERE, "tf_backend_emu.cpp"),
-               "-o", so + ".tmp"]
+               "-o", tmp]
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError("emulation build failed:\n" + res.stderr[-4000:])
-        os.replace(so + ".tmp", so)
+        os.replace(tmp, so)
     return so, spec
 
 

@@ -1619,6 +1619,7 @@ int tf_step_theta(tf_solver* s, int32_t src, int32_t dst, double dt, double thet
         s->slot_key(theta * dt);      // (a step that reuses a factorisation is another string of launches, on its buffers)
     s->prepare_step(theta * dt);
     s->run_graphed(key, s->step_graphable(theta * dt), [&] { step_theta(s, src, dst, dt, theta); });
+    s->mark_hooked(dst);          // (a replayed graph does not run the host side of the step)
     TF_API_END
 }
 
@@ -1637,6 +1638,7 @@ int tf_step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns,
     for (int i = 0; i < ns; ++i) key += bits_of(b[i]) + (b_pred ? bits_of(b_pred[i]) : std::string("-"));
     s->run_graphed(key, s->step_graphable(gamma[0] * dt), [&] {
         step_row(s, src, dst, dt, ns, alpha, gamma, b, b_pred, hook_after != 0, err_out != nullptr); });
+    if (hook_after) s->mark_hooked(dst); else s->slot_written(dst);     // (a replayed graph does not run the host side of the step)
     if (err_out) {
         *err_out = 0.0;
         if (b_pred) {
