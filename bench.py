@@ -390,9 +390,11 @@ def main():
         stages = len(ens.tab.b) if ens.tab is not None else 1
         bytes_per_launch = sweep_bytes_per_node(model) * N * len(mine)
         achieved = bytes_per_launch / (sweep_ms / sweep_n * 1e-3) / 1e9 if sweep_n else None
-        # Theta / BDF-2 run the sweep fused with their right-hand side: the kernel also writes
-        # rhs (8*nvar) and, for BDF-2, reads and rewrites the history U_{n-1} (16*nvar)
-        fused_extra = {"tfk_sweep_fj_theta": 8, "tfk_sweep_fj_bdf2": 24}.get(sweep_kernel, 0) * model._nvar
+        # Theta / BDF-2 run the sweep fused with their right-hand side: the kernel writes rhs (8*nvar)
+        # where the plain sweep writes F (F stays inside rhs) and, for BDF-2, reads and rewrites the
+        # history U_{n-1} (16*nvar)
+        fused = sweep_kernel in ("tfk_sweep_fj_theta", "tfk_sweep_fj_bdf2")
+        fused_extra = {"tfk_sweep_fj_theta": 0, "tfk_sweep_fj_bdf2": 16}.get(sweep_kernel, 0) * model._nvar
         fused_bytes = (sweep_bytes_per_node(model) + fused_extra) * N * len(mine)
         step_bytes = step_bytes_per_node(model, scheme, stages) * N * len(mine)
         step_gbs = step_bytes / elapsed * args.steps / 1e9
@@ -433,7 +435,7 @@ def main():
                               "formula": "SURVEY 8(d) implicit-step bytes: %d B/node" %
                                          step_bytes_per_node(model, scheme, stages)},
         }
-        if fused_extra and sweep_n:
+        if fused and sweep_n:
             out["roofline"]["fused_bytes_per_launch"] = fused_bytes
             out["roofline"]["fused_frac"] = fused_bytes / (sweep_ms / sweep_n * 1e-3) / 1e9 / HBM_PEAK_GBS
             out["roofline"]["fused_note"] = ("%s = F+J sweep + the scheme's right-hand side in one pass: 'frac' prices it by "

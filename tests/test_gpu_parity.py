@@ -244,11 +244,12 @@ def test_full_size_step_config5():
         assert np.isfinite(u).all()
         assert u[0, 0] == 1.0 and u[0, -1] == 1.0           # boundary values exact
     assert not np.array_equal(u1, u2)
-    # defining equation of the second step, with the F and J the step itself evaluated
-    # (still resident: F planes and the J @ v kernel of the same solver)
+    # defining equation of the second step, with the J the step itself evaluated (still resident:
+    # the J @ v kernel of the same solver) and F evaluated once more at the step's input (the fused
+    # sweep of the step leaves F inside its right-hand side; an F-only evaluation keeps J)
     N, nvar = fd["x"].size, m._nvar
     flat = lambda u: u.T.reshape(-1)
-    F1 = solver.get_F()[0]
+    F1 = np.asarray(m.F(f1, pars)).reshape(-1)
     d2 = flat(u2) - flat(u1)
     rhs = (flat(u1) - flat(u0)) / 3.0 + (2.0 / 3.0) * dt * F1
     res = (d2 - (2.0 / 3.0) * dt * solver.matvec(d2)[0] - rhs).reshape(N, nvar)

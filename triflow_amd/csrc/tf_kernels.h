@@ -259,9 +259,12 @@ TF_DEVICE void tfk_sweep_body(const TfSweepArgs& a, int pg, int seg) {
                     tf_stp(a.stage_rhs, v, L.plane, off, a.cF * (a.fscale * Fo[v]) + a.cA * acc[v]);
                 continue;
             }
+            // (the theta and BDF-2 sweeps leave F inside their right-hand side: nobody reads it alone)
+            if (!(THETA || BDF) || a.F) {
 #pragma unroll
-            for (int v = 0; v < TF_NVAR; ++v)
-                TF_STORE_STREAM((double*)((char*)(a.F + (int64_t)v * L.plane) + off), a.fscale * Fo[v]);
+                for (int v = 0; v < TF_NVAR; ++v)
+                    TF_STORE_STREAM((double*)((char*)(a.F + (int64_t)v * L.plane) + off), a.fscale * Fo[v]);
+            }
             if (WITH_J) {
                 double Jo[TF_NNZ > 0 ? TF_NNZ : 1];
                 tf_eval_J(w, par, dx, xc, Jo);

@@ -451,13 +451,16 @@ struct tf_solver {
                spec.sweep_block, &a, sizeof(a));
         if (with_j) { have_jac = true; have_factor = false; }
     }
+    // (the fused sweeps of the theta and BDF-2 steps do not store F next to the right-hand side it is
+    // part of; TRIFLOW_FUSED_STORE_F=1: A/B runs)
+    bool store_f_fused = false;
     // F, J, the BDF-2 right-hand side and the history update Uprev <- U in one pass
     void sweep_bdf2(const double* fields, bool two_step, double c0, double c1, double* rhs, double* prev) {
         TfSweepArgs a;
         std::memset(&a, 0, sizeof(a));
         a.fscale = 1.0;
         a.L = L1; a.fields = fields; a.helpers = helpers.p; a.parvec = parvec.p; a.parsca = parsca.p;
-        a.dx = dx.p; a.xcoord = xcoord.p; a.F = F.p; a.Jv = Jv.p; a.with_j = 1;
+        a.dx = dx.p; a.xcoord = xcoord.p; a.F = store_f_fused ? F.p : nullptr; a.Jv = Jv.p; a.with_j = 1;
         a.bdf_rhs = rhs; a.bdf_prev = prev; a.bdf_c0 = c0; a.bdf_c1 = c1; a.bdf_two_step = two_step ? 1 : 0;
         unsigned gx = sweep_gx(), gy = cdiv(L1.M, spec.seg);
         launch(TFK_SWEEP_FJ_BDF2, gx, gy, spec.sweep_block, &a, sizeof(a));
@@ -469,7 +472,7 @@ struct tf_solver {
         std::memset(&a, 0, sizeof(a));
         a.fscale = 1.0;
         a.L = L1; a.fields = fields; a.helpers = helpers.p; a.parvec = parvec.p; a.parsca = parsca.p;
-        a.dx = dx.p; a.xcoord = xcoord.p; a.F = F.p; a.Jv = Jv.p; a.with_j = 1;
+        a.dx = dx.p; a.xcoord = xcoord.p; a.F = store_f_fused ? F.p : nullptr; a.Jv = Jv.p; a.with_j = 1;
         a.theta_rhs = rhs; a.theta = theta; a.theta_dt = dt;
         unsigned gx = sweep_gx(), gy = cdiv(L1.M, spec.seg);
         launch(TFK_SWEEP_FJ_THETA, gx, gy, spec.sweep_block, &a, sizeof(a));
@@ -1099,6 +1102,7 @@ tf_solver* make_solver(tf_model* model, int64_t N, int32_t nsys, int32_t periodi
     if (const char* v = getenv("TRIFLOW_L1_FUSE_ASM")) s->l1_fuse_asm = atoi(v) != 0;
     if (const char* v = getenv("TRIFLOW_FUSE_UPDATE")) s->upd_fuse = atoi(v) != 0;
     if (const char* v = getenv("TRIFLOW_HOOK_IN_PLACE")) s->hook_in_place = atoi(v) != 0;
+    if (const char* v = getenv("TRIFLOW_FUSED_STORE_F")) s->store_f_fused = atoi(v) != 0;
     s->l1_respike = TF_RESPIKE_MODEL(sp.mp, sp.nvar) && (int64_t)N * nsys >= TF_RESPIKE_MIN_NODES;
     if (const char* v = getenv("TRIFLOW_L1_TWIST")) s->l1_twist = atoi(v) != 0 ? 1 : 0;
     if (const char* v = getenv("TRIFLOW_L1_RESPIKE"))                                   // A/B runs, tests
