@@ -268,7 +268,8 @@ def main():
     N = x.size
     model = Model(*workloads.model_args(name))
     ens = Ensemble(model, x, fields, pars, bool(pars["periodic"]), scheme=scheme,
-                   device=device_index, hook=config_hook(args.config), nstate=3)
+                   device=device_index, hook=config_hook(args.config),
+                   nstate=4 if scheme == "BDF2" else 3)   # (BDF-2: three rotating slots, the history is read in place)
     solver = ens.solver
 
     def barrier():

@@ -164,6 +164,9 @@ int tf_bdf2_reset(tf_solver*);
 int tf_step_bdf2_owned(tf_solver*, int32_t src, int32_t dst, double dt, int64_t owner,
                        int32_t continuing);
 int tf_bdf2_release(tf_solver*, int64_t owner);      /* frees that history buffer */
+/* the same step with the history in a state slot of the caller's: `prev` holds U_{n-1}, or is -1
+ * (first step, or the step size changed: backward-Euler form).  Nothing is copied. */
+int tf_step_bdf2_from(tf_solver*, int32_t src, int32_t dst, int32_t prev, double dt);
 /* One trial of the reference's universal step-doubling controller (schemes.py:33-66; it wraps
  * every scheme a Simulation builds, simulation.py:190-197) without a host round trip per
  * sub-step: a coarse step m*dt (src -> coarse), `nfine` fine steps dt (src -> tmp -> dst ...,

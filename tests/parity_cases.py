@@ -245,6 +245,39 @@ def check_respike(backend):
         assert np.isfinite(out[0]).all() and err <= 1e-10, (cfg, sch, err)
 
 
+def check_bdf2_history_in_place(backend):
+    """BDF-2 through an Ensemble with three rotating state slots or more reads U_{n-1} in the slot
+    the previous step started from (tf_step_bdf2_from: no copy of the history); with two slots the
+    solver keeps a copy (tf_step_bdf2).  The same states, bit for bit: fixed steps, a change of
+    the step size (the history is dropped: backward-Euler form), a restart, with and without hook."""
+    from triflow_amd.ensemble import Ensemble
+    for hook, N, nsys in ((DEVICE_HOOKS["cfg5"], 1203, 1), (None, 611, 2)):
+        name, fd, pars, dt, _ = corpus.config_inputs(5, N)
+        m = device_model(name, backend)
+        fields = {k: np.repeat(v[None, :], nsys, axis=0) * (1 + 0.01 * np.arange(nsys))[:, None]
+                  for k, v in fd.items() if k != "x"}
+        out = []
+        for nstate in (5, 4, 3):             # rotation over 4 and 3 slots (one keeps the start), over 2
+            ens = Ensemble(m, fd["x"], fields, pars, bool(pars["periodic"]), scheme="BDF2", hook=hook, nstate=nstate)
+            assert (ens._nrot >= 3) == (nstate >= 4)
+            states = []
+            for k in range(9):
+                ens.step(dt if k < 5 else 0.5 * dt)
+                if k in (0, 1, 4, 5, 8):
+                    ens.sync()
+                    states.append(ens.state().copy())
+            ens.restart()
+            for _ in range(3):
+                ens.step(dt)
+            ens.sync()
+            states.append(ens.state().copy())
+            ens.close()
+            out.append(states)
+        for other in out[1:]:
+            for a, b in zip(out[0], other):
+                assert np.isfinite(a).all() and np.array_equal(a, b)
+
+
 def check_hook_input_in_place(backend):
     """A step with a Dirichlet hook starts from a copy of the state with the hook applied
     (schemes.py:144-145, 548-549).  The device skips the copy when the source slot is what an

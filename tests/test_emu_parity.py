@@ -142,6 +142,10 @@ def test_ensemble_restart(backend):
     pc.check_ensemble_restart(backend)
 
 
+def test_bdf2_history_in_place(backend):
+    pc.check_bdf2_history_in_place(backend)
+
+
 def test_hook_input_in_place(backend):
     pc.check_hook_input_in_place(backend)
 

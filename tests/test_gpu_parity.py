@@ -506,6 +506,10 @@ def test_ensemble_restart():
     pc.check_ensemble_restart(HIP)
 
 
+def test_bdf2_history_in_place():
+    pc.check_bdf2_history_in_place(HIP)
+
+
 def test_hook_input_in_place():
     pc.check_hook_input_in_place(HIP)
 

@@ -76,6 +76,7 @@ SIGNATURES = {
                               c_double_p]),
     "tf_step_bdf2": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double]),
     "tf_bdf2_reset": (C.c_int, [C.c_void_p]),
+    "tf_step_bdf2_from": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double]),
     "tf_step_bdf2_owned": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_int64,
                                      C.c_int32]),
     "tf_bdf2_release": (C.c_int, [C.c_void_p, C.c_int64]),
@@ -370,6 +371,10 @@ class DeviceSolver:
                           int(bool(continuing)))
         else:
             self.lib.call("tf_step_bdf2", self.handle, src, dst, float(dt))
+
+    def step_bdf2_from(self, src, dst, prev, dt):
+        """BDF-2 step whose history U_{n-1} is in state slot ``prev`` (-1: none, backward-Euler form)."""
+        self.lib.call("tf_step_bdf2_from", self.handle, src, dst, int(prev), float(dt))
 
     def bdf2_release(self, owner):
         if self.handle:

@@ -50,8 +50,11 @@ struct TfSweepArgs {               // F / F+J stencil sweep, J @ v, A-row build
     double theta, theta_dt;
     // tfk_sweep_fj_bdf2: right-hand side of the linearly implicit BDF-2 step and the history
     // update in the same pass:  rhs = c0*(U - Uprev) + c1*F (two_step) or c1*F;  Uprev <- U
+    // (bdf_prev_out NULL: the history is not copied -- the caller keeps U_n in a state slot of its
+    // own, tf_step_bdf2_from)
     double* bdf_rhs;
-    double* bdf_prev;
+    const double* bdf_prev;
+    double* bdf_prev_out;
     double bdf_c0, bdf_c1;
     int bdf_two_step;
     // tfk_sweep_f_stage_rhs: the right-hand side of Rosenbrock stage i in the pass that evaluates

@@ -279,7 +279,7 @@ TF_DEVICE void tfk_sweep_body(const TfSweepArgs& a, int pg, int seg) {
                         const int64_t q = (int64_t)v * L.plane + s;
                         a.bdf_rhs[q] = a.bdf_two_step ? a.bdf_c0 * (u - a.bdf_prev[q]) + a.bdf_c1 * Fo[v]
                                                       : a.bdf_c1 * Fo[v];
-                        a.bdf_prev[q] = u;
+                        if (a.bdf_prev_out) a.bdf_prev_out[q] = u;
                     }
                 }
                 if (THETA) {

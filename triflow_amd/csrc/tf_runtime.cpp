@@ -455,13 +455,14 @@ struct tf_solver {
     // part of; TRIFLOW_FUSED_STORE_F=1: A/B runs)
     bool store_f_fused = false;
     // F, J, the BDF-2 right-hand side and the history update Uprev <- U in one pass
-    void sweep_bdf2(const double* fields, bool two_step, double c0, double c1, double* rhs, double* prev) {
+    void sweep_bdf2(const double* fields, bool two_step, double c0, double c1, double* rhs,
+                    const double* prev, double* prev_out) {
         TfSweepArgs a;
         std::memset(&a, 0, sizeof(a));
         a.fscale = 1.0;
         a.L = L1; a.fields = fields; a.helpers = helpers.p; a.parvec = parvec.p; a.parsca = parsca.p;
         a.dx = dx.p; a.xcoord = xcoord.p; a.F = store_f_fused ? F.p : nullptr; a.Jv = Jv.p; a.with_j = 1;
-        a.bdf_rhs = rhs; a.bdf_prev = prev; a.bdf_c0 = c0; a.bdf_c1 = c1; a.bdf_two_step = two_step ? 1 : 0;
+        a.bdf_rhs = rhs; a.bdf_prev = prev; a.bdf_prev_out = prev_out; a.bdf_c0 = c0; a.bdf_c1 = c1; a.bdf_two_step = two_step ? 1 : 0;
         unsigned gx = sweep_gx(), gy = cdiv(L1.M, spec.seg);
         launch(TFK_SWEEP_FJ_BDF2, gx, gy, spec.sweep_block, &a, sizeof(a));
         have_jac = true; have_factor = false;
@@ -1705,18 +1706,31 @@ int tf_step_doubling(tf_solver* s, int32_t src, int32_t dst, int32_t tmp, int32_
 //   (I -     dt J)(U+ - U) = dt F                           first step / dt changed
 }  // extern "C"
 namespace {
-void step_bdf2(tf_solver* s, int32_t src, int32_t dst, double dt, tf_solver::BdfHist& h, bool continuing) {
+// prev_slot >= 0: U_{n-1} is in that state slot (the caller rotates three slots or more and says
+// where; nothing is copied); -1: this step has no history (backward-Euler form); -2: the history
+// buffer `h` of the solver / of a scheme object, updated by the sweep
+void step_bdf2(tf_solver* s, int32_t src, int32_t dst, double dt, tf_solver::BdfHist* h, bool continuing,
+               int32_t prev_slot = -2) {
     require(src != dst, "tf_step_bdf2: src and dst slots must differ");
-    if (h.Uprev.n == 0) h.Uprev.alloc((size_t)s->vecn(), s->bytes);     // history buffers are made on first use
     double* U = s->st(dst);
     s->slot_written(dst);
     const double* Uin = s->stage_input(src, U);
-    const bool two_step = continuing && h.have_prev &&
-        std::fabs(h.dt_prev - dt) <= 1e-12 * std::fabs(dt);
+    bool two_step;
+    const double* prev = nullptr;
+    double* prev_out = nullptr;
+    if (h) {
+        if (h->Uprev.n == 0) h->Uprev.alloc((size_t)s->vecn(), s->bytes);   // history buffers are made on first use
+        two_step = continuing && h->have_prev && std::fabs(h->dt_prev - dt) <= 1e-12 * std::fabs(dt);
+        prev = prev_out = h->Uprev.p;
+        h->have_prev = true;
+        h->dt_prev = dt;
+    } else {
+        require(prev_slot != src && prev_slot != dst, "tf_step_bdf2_from: the history slot must differ from src and dst");
+        two_step = prev_slot >= 0;
+        prev = two_step ? s->st(prev_slot) : nullptr;
+    }
     // rhs = 1/3 (U - Uprev) + 2/3 dt F (two-step) or dt F (first step), and Uprev <- U
-    s->sweep_bdf2(Uin, two_step, 1.0 / 3.0, two_step ? (2.0 / 3.0) * dt : dt, s->Wrhs.p, h.Uprev.p);
-    h.have_prev = true;
-    h.dt_prev = dt;
+    s->sweep_bdf2(Uin, two_step, 1.0 / 3.0, two_step ? (2.0 / 3.0) * dt : dt, s->Wrhs.p, prev, prev_out);
     s->request_update(U, Uin, nullptr, 1.0, 0.0, 1);               // (1.0 * x == x: the sum of TF_VEC_ADD)
     s->factor_step(two_step ? (2.0 / 3.0) * dt : dt, s->Wrhs.p, s->Wdel.p);
     const double* ys[2] = {Uin, s->Wdel.p};
@@ -1729,7 +1743,7 @@ extern "C" {
 int tf_step_bdf2(tf_solver* s, int32_t src, int32_t dst, double dt) {
     TF_API_BEGIN
     require(s, "null solver");
-    step_bdf2(s, src, dst, dt, s->bdf0, true);
+    step_bdf2(s, src, dst, dt, &s->bdf0, true);
     TF_API_END
 }
 // The same step for a scheme object that shares the solver with others: `owner` names its
@@ -1741,7 +1755,18 @@ int tf_step_bdf2_owned(tf_solver* s, int32_t src, int32_t dst, double dt, int64_
     require(owner != 0, "tf_step_bdf2_owned: owner id 0 is the solver's own history (tf_step_bdf2)");
     auto& slot = s->bdf_owned[owner];
     if (!slot) slot.reset(new tf_solver::BdfHist());
-    step_bdf2(s, src, dst, dt, *slot, continuing != 0);
+    step_bdf2(s, src, dst, dt, slot.get(), continuing != 0);
+    TF_API_END
+}
+// The same step with the history in a state slot of the caller: `prev` holds U_{n-1} (the state
+// the previous step of the same size started from), or is -1 for a first step / after a change of
+// dt (backward-Euler form).  Nothing is copied: a caller that rotates three slots or more saves
+// the pass over the history (config 5: 160 MB written per step).
+int tf_step_bdf2_from(tf_solver* s, int32_t src, int32_t dst, int32_t prev, double dt) {
+    TF_API_BEGIN
+    require(s, "null solver");
+    require(prev >= -1, "tf_step_bdf2_from: prev is a state slot or -1");
+    step_bdf2(s, src, dst, dt, nullptr, true, prev);
     TF_API_END
 }
 int tf_bdf2_reset(tf_solver* s) {

@@ -94,6 +94,10 @@ class Ensemble:
         self.scheme, self.theta = scheme, theta
         self.tab = TABLEAUX.get(scheme)
         self.cur, self.t = 0, 0.0
+        # BDF-2 with three rotating slots or more: U_{n-1} is still in the slot the previous step
+        # started from -- the step reads it there and the history is never copied (tf_step_bdf2_from)
+        self._nrot = s.nstate if self._keep is None else self._keep
+        self._bdf_prev, self._bdf_dt = -1, None
 
     def step(self, dt):
         """One fixed step of every member (asynchronous: returns after the launches)."""
@@ -101,6 +105,10 @@ class Ensemble:
         dst = (src + 1) % (s.nstate if self._keep is None else self._keep)
         if self.scheme == "Theta":
             s.step_theta(src, dst, dt, self.theta)
+        elif self.scheme == "BDF2" and self._nrot >= 3:
+            same = self._bdf_dt is not None and abs(self._bdf_dt - dt) <= 1e-12 * abs(dt)
+            s.step_bdf2_from(src, dst, self._bdf_prev if same else -1, dt)
+            self._bdf_prev, self._bdf_dt = src, dt
         elif self.scheme == "BDF2":
             s.step_bdf2(src, dst, dt)
         else:
@@ -118,6 +126,7 @@ class Ensemble:
         self.solver.copy_state(self._keep, 0)
         if self.scheme == "BDF2":
             self.solver.bdf2_reset()
+            self._bdf_prev, self._bdf_dt = -1, None
         self.cur, self.t = 0, 0.0
 
     def sync(self):
