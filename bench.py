@@ -392,10 +392,10 @@ def main():
         bytes_per_launch = sweep_bytes_per_node(model) * N * len(mine)
         achieved = bytes_per_launch / (sweep_ms / sweep_n * 1e-3) / 1e9 if sweep_n else None
         # Theta / BDF-2 run the sweep fused with their right-hand side: the kernel writes rhs (8*nvar)
-        # where the plain sweep writes F (F stays inside rhs) and, for BDF-2, reads and rewrites the
-        # history U_{n-1} (16*nvar)
+        # where the plain sweep writes F (F stays inside rhs) and, for BDF-2, reads the history
+        # U_{n-1} in its state slot (8*nvar; with two rotating slots it would also copy it)
         fused = sweep_kernel in ("tfk_sweep_fj_theta", "tfk_sweep_fj_bdf2")
-        fused_extra = {"tfk_sweep_fj_theta": 0, "tfk_sweep_fj_bdf2": 16}.get(sweep_kernel, 0) * model._nvar
+        fused_extra = {"tfk_sweep_fj_theta": 0, "tfk_sweep_fj_bdf2": 8 if ens._nrot >= 3 else 16}.get(sweep_kernel, 0) * model._nvar
         fused_bytes = (sweep_bytes_per_node(model) + fused_extra) * N * len(mine)
         step_bytes = step_bytes_per_node(model, scheme, stages) * N * len(mine)
         step_gbs = step_bytes / elapsed * args.steps / 1e9
