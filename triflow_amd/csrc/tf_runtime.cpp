@@ -1583,7 +1583,10 @@ void step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns, con
 // download (one host wait for a whole step-doubling trial) and are looked at like tf_sync does
 void diff_norm(tf_solver* s, int32_t slot_a, int32_t slot_b, int32_t ord, double* out, bool with_status = false) {
     require(ord == 0 || ord == 2, "tf_diff_norm: ord must be 2 or 0 (max norm)");
-    const int nb = 64, nvs = s->spec.nvar * s->nsys;
+    // (enough workgroups to fill the GPU whatever the number of variables and members: 64 of them
+    // took 32 us for the two 8 MB states of config 2; the host adds the partial sums in a fixed order)
+    const int nvs = s->spec.nvar * s->nsys;
+    const int nb = std::min(1024, std::max(64, 2048 / std::max(nvs, 1)));
     if (s->normbuf.n < (size_t)nb * nvs + 2) s->normbuf.alloc((size_t)nb * nvs + 2, s->bytes);
     TfNormArgs a;
     a.L = s->L1; a.a = s->st(slot_a); a.b = s->st(slot_b); a.partial = s->normbuf.p;
