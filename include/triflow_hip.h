@@ -124,6 +124,9 @@ int tf_peek(tf_solver*, int32_t slot, int32_t n, const int32_t* var, const int64
 int tf_eval(tf_solver*, int32_t slot, int32_t with_j);
 /* `reps` back-to-back sweeps between two HIP events on the solver's stream */
 int tf_eval_repeat(tf_solver*, int32_t slot, int32_t with_j, int32_t reps, double* total_ms);
+/* F of the last tf_eval.  After a step function the F buffer is unspecified: the fused sweeps of
+ * the theta and BDF-2 steps fold F into the right-hand side they write and leave the buffer alone,
+ * a ROW step leaves dt*F there.  Call tf_eval before tf_get_F. */
 int tf_get_F(tf_solver*, double* F /*[nsys][N*nvar], F[node*nvar+eq]*/);
 int tf_get_J(tf_solver*, double* Jvals /*[nsys][N][nnz], reference pattern order*/);
 
@@ -165,7 +168,10 @@ int tf_step_bdf2_owned(tf_solver*, int32_t src, int32_t dst, double dt, int64_t 
                        int32_t continuing);
 int tf_bdf2_release(tf_solver*, int64_t owner);      /* frees that history buffer */
 /* the same step with the history in a state slot of the caller's: `prev` holds U_{n-1}, or is -1
- * (first step, or the step size changed: backward-Euler form).  Nothing is copied. */
+ * (first step, or the step size changed: backward-Euler form).  Nothing is copied.  With Dirichlet
+ * values set, `src` is the next step's history and must hold the *hooked* state (the reference's
+ * schemes keep the hooked copy): unless a step of this solver left it so, the boundary values are
+ * written into slot `src` in place -- the one step function that modifies its input slot. */
 int tf_step_bdf2_from(tf_solver*, int32_t src, int32_t dst, int32_t prev, double dt);
 /* One trial of the reference's universal step-doubling controller (schemes.py:33-66; it wraps
  * every scheme a Simulation builds, simulation.py:190-197) without a host round trip per

@@ -105,7 +105,13 @@ void launch(Module*, int kernel, unsigned gx, unsigned gy, unsigned block,
         *a.red = m; } break;
     case TFK_DIFFNORM: { const auto& a = *(const TfNormArgs*)args;
         for (unsigned y = 0; y < gy; ++y) for (unsigned b = 0; b < gx; ++b)
-            a.partial[(int64_t)y * a.nblocks + b] = tfk_diffnorm_partial(a, (int)y, (int)b, 0, 1); } break;
+            a.partial[(int64_t)y * a.nblocks + b] = tfk_diffnorm_partial(a, (int)y, (int)b, 0, 1);
+        if (a.status) {
+            double* tail = a.partial + (int64_t)gy * a.nblocks;
+            unsigned long long bits = (unsigned)*a.status;
+            std::memcpy(&tail[0], &bits, sizeof(double));
+            tail[1] = *a.mon;
+        } } break;
     case TFK_PERM: { const auto& a = *(const TfPermArgs*)args;
         for (int64_t t = 0; t < nthreads; ++t) tfk_perm_elem(a, t); } break;
     case TFK_GATHER: { const auto& a = *(const TfGatherArgs*)args;

@@ -278,6 +278,55 @@ def check_bdf2_history_in_place(backend):
                 assert np.isfinite(a).all() and np.array_equal(a, b)
 
 
+def check_bdf2_history_is_the_hooked_state(backend):
+    """The history of a BDF-2 step is the *hooked* input of the step before (the oracle keeps the
+    hooked copy, oracle/numpy_path.py BDF2._prev).  An initial -- or uploaded -- state whose boundary
+    nodes differ from the hook's values: the rotation over state slots (tf_step_bdf2_from) against the
+    oracle scheme and against the copied history, including a state uploaded between two steps."""
+    from triflow_amd.ensemble import Ensemble
+    N = 301
+    name, fd, pars, dt, _ = corpus.config_inputs(5, N)
+    hook_values = {0: 2.0, -1: 2.0}                       # the initial A is 1 everywhere
+    hook = DirichletHook(A=dict(hook_values))
+    def ora_hook(t, fields, pars):
+        for node, value in hook_values.items():
+            fields["A"][node] = value
+        return fields, pars
+    m, mo = device_model(name, backend), oracle_model(name)
+    sch = ora.BDF2(mo)
+    fo = mo.fields_template(**fd)
+    ref = []
+    t = 0.0
+    for k in range(4):
+        t, fo = sch(t, fo, dt, pars, hook=ora_hook)
+        ref.append(np.array([np.asarray(fo[v]) for v in mo._dep_vars]))
+    fields = {k: v[None, :] for k, v in fd.items() if k != "x"}
+    for nstate in (4, 3):
+        ens = Ensemble(m, fd["x"], fields, pars, bool(pars["periodic"]), scheme="BDF2", hook=hook, nstate=nstate)
+        for k in range(4):
+            ens.step(dt)
+            ens.sync()
+            got = ens.state()[:, 0, :]
+            err = np.abs(got - ref[k]).max() / np.abs(ref[k]).max()
+            assert err <= 1e-9, (nstate, k, err)
+        ens.close()
+    # a state uploaded between two steps (its boundary nodes violate the hook again): the step after
+    # the upload still uses the hooked upload as U_n and the hooked U_{n-1} as history
+    outs = []
+    for nstate in (4, 3):
+        ens = Ensemble(m, fd["x"], fields, pars, bool(pars["periodic"]), scheme="BDF2", hook=hook, nstate=nstate)
+        ens.step(dt); ens.step(dt); ens.sync()
+        up = ens.state().copy()
+        up[0, :, 0] = 1.5
+        up[0, :, -1] = 0.5
+        ens.solver.set_state(ens.cur, up)
+        ens.step(dt); ens.step(dt); ens.sync()
+        outs.append(ens.state().copy())
+        ens.close()
+    assert np.isfinite(outs[0]).all()
+    assert np.abs(outs[0] - outs[1]).max() <= 1e-12 * np.abs(outs[1]).max()
+
+
 def check_hook_input_in_place(backend):
     """A step with a Dirichlet hook starts from a copy of the state with the hook applied
     (schemes.py:144-145, 548-549).  The device skips the copy when the source slot is what an

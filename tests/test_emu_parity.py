@@ -146,6 +146,10 @@ def test_bdf2_history_in_place(backend):
     pc.check_bdf2_history_in_place(backend)
 
 
+def test_bdf2_history_is_the_hooked_state(backend):
+    pc.check_bdf2_history_is_the_hooked_state(backend)
+
+
 def test_hook_input_in_place(backend):
     pc.check_hook_input_in_place(backend)
 

@@ -510,6 +510,10 @@ def test_bdf2_history_in_place():
     pc.check_bdf2_history_in_place(HIP)
 
 
+def test_bdf2_history_is_the_hooked_state():
+    pc.check_bdf2_history_is_the_hooked_state(HIP)
+
+
 def test_hook_input_in_place():
     pc.check_hook_input_in_place(HIP)
 

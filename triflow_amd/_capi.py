@@ -433,6 +433,13 @@ class DeviceSolver:
 
     def sync(self):
         self.lib.call("tf_sync", self.handle)
+        if not getattr(self, "_warned_replan", False) and self.counters()["replans"]:
+            import warnings
+            self._warned_replan = True
+            warnings.warn("banded solver: the default partition lost accuracy on this matrix and the "
+                          "factorisations go through the rescue plan (8 x longer chunks, every solve "
+                          "checked): several times slower; see DESIGN.md section 4.5", RuntimeWarning,
+                          stacklevel=2)
 
     def debug_stamps(self, levels=8):
         """[levels][64] uint64 stamps of a -DTF_STAMPS kernel build (first call: switch on)."""

@@ -97,6 +97,10 @@ struct TfNormArgs {               // per-variable, per-system norm of (a - b): p
     double* partial;               // [nvar*nsys][nblocks]
     int nblocks;
     int ord;                       // 2: sum of squares, 0: max |.|
+    // non-NULL: the failure flag and the monitor's worst value ride along behind the partials
+    // (partial[nvar*nsys*nblocks], [.. + 1]): one download, one host wait per trial
+    const int* status;
+    const double* mon;
 };
 
 struct TfBerrArgs {               // componentwise backward error of (I - cJ) x = b

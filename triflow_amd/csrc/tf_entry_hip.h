@@ -176,6 +176,12 @@ __global__ void __launch_bounds__(256) tfk_diffnorm(TfNormArgs a) {
         for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
             acc = a.ord == 2 ? acc + part[w] : (part[w] > acc ? part[w] : acc);
         a.partial[(int64_t)blockIdx.y * a.nblocks + blockIdx.x] = acc;
+        if (a.status && blockIdx.x == 0 && blockIdx.y == 0) {
+            double* tail = a.partial + (int64_t)gridDim.y * a.nblocks;
+            unsigned long long bits = (unsigned)*a.status;
+            tail[0] = __longlong_as_double((long long)bits);
+            tail[1] = *a.mon;
+        }
     }
 }
 

@@ -629,10 +629,10 @@ struct tf_solver {
     std::vector<double> dir_h, dir_post_h;         // host mirrors of dir_val / dir_val_post
     bool hook_in_place = true;                     // (TRIFLOW_HOOK_IN_PLACE=0: A/B runs, tests)
     void slot_written(int slot) { if (slot >= 0 && (size_t)slot < slot_hook.size()) slot_hook[slot].clear(); }
-    void mark_hooked(int slot) {
+    void mark_hooked(int slot, bool post = true) {
         if (slot < 0) return;
         if ((size_t)slot >= slot_hook.size()) slot_hook.resize((size_t)slot + 1);
-        slot_hook[slot] = dir_post_h;
+        slot_hook[slot] = post ? dir_post_h : dir_h;
     }
     bool input_is_hooked(int src) const {
         return hook_in_place && ndir > 0 && src >= 0 && (size_t)src < slot_hook.size() &&
@@ -909,8 +909,10 @@ struct tf_solver {
     double fb_c = 0.0;
     uint64_t fb_ver = 0;
     bool fb_valid = false;
+    bool fb_touched = false;       // the child ran since this solver last looked at its status
     void delegate_factor(double c) {
         tf_solver* fb = ensure_fallback();
+        fb_touched = true;
         fb->mode = mode;
         copy(fb->parsca.p, parsca.p, parsca.n * sizeof(double));
         copy(fb->dx.p, dx.p, (size_t)nsys * sizeof(double));
@@ -927,6 +929,7 @@ struct tf_solver {
     void delegate_solve(const double* rhs1, double* x1) {
         if (!(fb_valid && fb_c == factor_c && fb_ver == par_ver)) delegate_factor(factor_c);
         tf_solver* fb = fallback;
+        fb_touched = true;
         fb->mode = mode;
         transfer_to(fb, rhs1, fb->Wrhs.p, spec.nvar);
         fb->solve(fb->Wrhs.p, fb->Wstage.p);
@@ -1014,7 +1017,8 @@ struct tf_solver {
             tfb::memset0(status, sizeof(int), stream);
             throw std::runtime_error("banded solver: singular or non-finite pivot block");
         }
-        if (fallback) fallback->check_status();
+        // (the child's flag costs a blocking read of its own: only when it ran since the last look)
+        if (fallback && fb_touched) { fb_touched = false; fallback->check_status(); }
         if (unstable) {
             unstable = false;
             throw std::runtime_error("banded solver: the block elimination lost accuracy (backward error " +
@@ -1591,12 +1595,9 @@ void diff_norm(tf_solver* s, int32_t slot_a, int32_t slot_b, int32_t ord, double
     TfNormArgs a;
     a.L = s->L1; a.a = s->st(slot_a); a.b = s->st(slot_b); a.partial = s->normbuf.p;
     a.nblocks = nb; a.ord = ord;
+    a.status = with_status ? s->status : nullptr; a.mon = with_status ? s->red.p + 4 : nullptr;
     s->launch(TFK_DIFFNORM, nb, nvs, 256, &a, sizeof(a));
     std::vector<double> part((size_t)nb * nvs + 2);
-    if (with_status) {
-        tfb::d2d(s->normbuf.p + (size_t)nb * nvs, s->status, sizeof(int), s->stream);
-        tfb::d2d(s->normbuf.p + (size_t)nb * nvs + 1, s->red.p + 4, sizeof(double), s->stream);
-    }
     tfb::d2h(part.data(), s->normbuf.p, ((size_t)nb * nvs + (with_status ? 2 : 0)) * sizeof(double), s->stream);
     if (with_status) {
         int flag = 0;
@@ -1690,9 +1691,9 @@ int tf_step_doubling(tf_solver* s, int32_t src, int32_t dst, int32_t tmp, int32_
         from = to;
     }
     std::vector<double> norms((size_t)s->nsys * s->spec.nvar);
-    // the one synchronisation: the norms.  (Device-side failures surface at the next synchronising
-    // call, as for a trial driven step by step: no second wait, no extra copies here.)
-    diff_norm(s, coarse, dst, ord, norms.data());
+    // the one synchronisation: the norms; the failure flag and the monitor's worst value come back
+    // in the same download (written behind the partial sums by the norm kernel itself)
+    diff_norm(s, coarse, dst, ord, norms.data(), true);
     for (int e = 0; e < s->nsys; ++e) {
         double worst = 0.0;
         for (int v = 0; v < s->spec.nvar; ++v) {
@@ -1717,7 +1718,18 @@ void step_bdf2(tf_solver* s, int32_t src, int32_t dst, double dt, tf_solver::Bdf
     require(src != dst, "tf_step_bdf2: src and dst slots must differ");
     double* U = s->st(dst);
     s->slot_written(dst);
-    const double* Uin = s->stage_input(src, U);
+    const double* Uin;
+    if (!h && s->ndir > 0 && !s->input_is_hooked(src)) {
+        // The history of the next step is this step's *hooked* input (the oracle keeps the hooked
+        // copy, oracle/numpy_path.py BDF2._prev), and with the history in a state slot that slot is
+        // src itself: the boundary values go into src in place (no copy into dst) and the slot is
+        // remembered as satisfying them.
+        s->apply_dirichlet(s->st(src));
+        s->mark_hooked(src, false);
+        Uin = s->st(src);
+    } else {
+        Uin = s->stage_input(src, U);
+    }
     bool two_step;
     const double* prev = nullptr;
     double* prev_out = nullptr;
