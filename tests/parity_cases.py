@@ -439,6 +439,64 @@ def check_steps_golden(case, backend, python_hook=False, only=None):
         assert np.isclose(t, 5 * dt)
 
 
+def check_adaptive_landing_reuse(backend):
+    """The default user path: adaptive Rosenbrock steps driven to a target (schemes.py:176-238).  Once the
+    controller's own step exceeds the caller's dt, the reference's landing step repeats the accepted
+    trial with a dt that differs by the rounding of t + dt; the device scheme takes the trial's state
+    instead (ROW_general.REUSE_TRIAL_AS_LANDING): same states to 1e-13 as the literal sequence, half the
+    Rosenbrock steps -- no hook, the declarative hook, a Python hook (never reused).  And a
+    constant-matrix Theta scheme driven by Simulation (dt = target - t, an ulp off the last one) keeps its
+    factorisation."""
+    from triflow_amd import _capi
+    calls = {"row": 0}
+    orig = _capi.DeviceSolver.step_row
+
+    def counting(self, *a, **k):
+        calls["row"] += 1
+        return orig(self, *a, **k)
+    _capi.DeviceSolver.step_row = counting
+    try:
+        for cfg, N, hook in ((3, 400, None), (1, 200, DEVICE_HOOKS["cfg1"]), (1, 200, HOOKS["cfg1"])):
+            name, fd, pars, dt, _ = corpus.config_inputs(cfg, N)
+            m = device_model(name, backend)
+            out, counts = [], []
+            for reuse in (True, False):
+                scheme = schemes.RODASPR(m, tol=1e-1)
+                scheme.REUSE_TRIAL_AS_LANDING = reuse
+                f, t = m.fields_template(**fd), 0.3
+                kw = {"hook": hook} if hook is not None else {}
+                calls["row"] = 0
+                states = []
+                with np.errstate(all="ignore"):
+                    for k in range(14):
+                        t, f = scheme(t, f, dt, pars, **kw)
+                        states.append(f.uflat.copy())
+                out.append(states)
+                counts.append(calls["row"])
+            for a, b in zip(*out):
+                assert np.isfinite(a).all()
+                assert np.abs(a - b).max() <= 1e-13 * np.abs(b).max(), (cfg, np.abs(a - b).max())
+            if hook is HOOKS["cfg1"]:
+                assert counts[0] == counts[1]                  # a Python hook: the literal sequence
+            else:
+                assert counts[0] < counts[1], counts           # fewer Rosenbrock steps
+                assert counts[1] - counts[0] >= 3, counts      # ... by one per call once the controller's step exceeds dt
+    finally:
+        _capi.DeviceSolver.step_row = orig
+    # Simulation -> Theta on the constant-matrix model: one factorisation serves every landing step
+    name, fd, pars, dt, _ = corpus.config_inputs(2, 2000)
+    m = device_model(name, backend)
+    sim = Simulation(m, dict(fd), pars, dt, scheme=schemes.Theta, time_stepping=False)
+    it = iter(sim)
+    for _ in range(3):
+        next(it)
+    solver = sim.fields._device_backing().stepper.solver
+    c0 = solver.counters()["factorisations"]
+    for _ in range(12):
+        next(it)
+    assert solver.counters()["factorisations"] == c0
+
+
 def check_bdf2(backend):
     """BDF-2 (not in the reference): device scheme against the oracle's
     restatement, same F/J, SuperLU vs banded solver."""

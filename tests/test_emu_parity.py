@@ -181,3 +181,7 @@ def test_python_hook_stays_resident(backend):
 
 def test_neumann_python_hook(backend):
     pc.check_neumann_python_hook(backend)
+
+
+def test_adaptive_landing_reuse(backend):
+    pc.check_adaptive_landing_reuse(backend)

@@ -684,3 +684,7 @@ def test_python_hook_stays_resident():
 
 def test_neumann_python_hook():
     pc.check_neumann_python_hook(HIP)
+
+
+def test_adaptive_landing_reuse():
+    pc.check_adaptive_landing_reuse(HIP)

@@ -43,15 +43,14 @@ for l in range(1, len(s.describe()["chunks"])):
     total, real = r[21] - r[0], (r[31] - r[30]) / 100.0        # s_memrealtime: 100 MHz
     marks = [r[0], r[1]] + [v for v in r[2:20] if v] + [r[20], r[21]]
     d = np.diff(marks)
-    print("level %d: %d cycles = %.2f us (clock %.2f GHz)  load %d | rounds (A, B): %s | share %d | fold/end %d"
+    print("level %d: %d cycles = %.2f us (clock %.2f GHz)  load %d | rounds (tasks, barrier): %s | share %d | fold/end %d"
           % (l + 1, total, real, total / real / 1e3 if real else 0, d[0],
              " ".join("(%d, %d)" % (d[1 + 2 * i], d[2 + 2 * i]) for i in range((len(d) - 3) // 2)), d[-2], d[-1]))
-    if r[44]:
-        print("         round 2, wavefront 0: phase A starts %d cycles after the barrier; block inversion (load + eliminate) %d, stores %d"
-              % (r[44] - marks[3], r[45] - r[44], r[46] - r[45]))
-    if r[47]:
-        print("         round 2, wavefront 0: phase B prologue (old values, stored blocks) %d cycles after the barrier, products %d, then stores + barrier %d"
-              % (r[47] - marks[4], r[48] - r[47], marks[5] - r[48]))
+    if r[44] and r[47]:
+        # (tf_cr3_hip.h: one task per node and round; the two marks of a round are "tasks done" and "barrier passed")
+        print("         round 2, wavefront 0: task starts %d cycles after the barrier; old values + block inversion %d, "
+              "record stores %d, products %d, neighbour stores %d, until the barrier is passed %d"
+              % (r[44] - marks[3], r[45] - r[44], r[46] - r[45], r[47] - r[46], r[48] - r[47], marks[5] - r[48]))
     if r[50]:
         print("         tail kernel (this level + the last one): " + " ".join(str(int(v)) for v in np.diff(r[50:57])) + " cycles (requests, forward, park, last level, barrier, backward)")
     if r[41]:

@@ -48,7 +48,7 @@ HIPCC_FLAGS = [*os.environ.get("TRIFLOW_HIPCC_OPT", "-O3").split(), "-std=c++17"
                "-ffp-contract=off", "--offload-arch=" + GPU_ARCH,
                *os.environ.get("TRIFLOW_HIPCC_EXTRA", "").split()]
 
-_SKELETON = ("tf_args.h", "tf_math.h", "tf_kernels.h", "tf_crs.h", "tf_coop_hip.h", "tf_cr2_hip.h", "tf_entry_hip.h")
+_SKELETON = ("tf_args.h", "tf_math.h", "tf_kernels.h", "tf_crs.h", "tf_coop_hip.h", "tf_cr2_hip.h", "tf_cr3_hip.h", "tf_entry_hip.h")
 _TU_HEAD = ('#include <hip/hip_runtime.h>\n'
             '#define TF_DEVICE __device__ __forceinline__\n'
             '%s'

@@ -6,6 +6,7 @@
 
 #include "tf_coop_hip.h"
 #include "tf_cr2_hip.h"
+#include "tf_cr3_hip.h"
 
 #define TF_GID ((int)(blockIdx.x * blockDim.x + threadIdx.x))
 
@@ -339,12 +340,16 @@ __global__ void __launch_bounds__(64) tfk_tiny_solve(TfTinyArgs a) { tfk_tiny_so
 #define TF_CR_BLOCK (TF_B2 <= 2 ? 256 : 64)
 // the factorisation of 3 <= b <= 8: up to 8 wavefronts per chunk (tf_cr2_hip.h)
 #define TF_CR_FACTOR_BLOCK (TF_B2 <= 2 ? 256 : 512)
+#ifndef TF_CR_V4
+#define TF_CR_V4 1                 // 0: the round-3 factorisation (tf_cr2_hip.h) for every block size (A/B runs)
+#endif
 #ifndef TF_CR_FACTOR_WAVES
 #define TF_CR_FACTOR_WAVES 4       // wavefronts per SIMD the register allocator makes room for
 #endif
 __global__ void __attribute__((amdgpu_waves_per_eu(TF_CR_FACTOR_WAVES))) __launch_bounds__(TF_CR_FACTOR_BLOCK)
 tfk_cr_factor(TfLevelArgs a) {
     if constexpr (TF_B2 <= 2) tfk_crs_factor<TF_B2, 256>(a, (int)blockIdx.x, (int)threadIdx.x);
+    else if constexpr (TF_B2 <= 7 && TF_CR_V4) tfk_cr_factor_v4<TF_B2>(a);
     else if constexpr (TF_B2 <= 8) tfk_cr_factor_v3<TF_B2>(a);
 }
 __global__ void __launch_bounds__(TF_CR_BLOCK) tfk_cr_fwd(TfLevelArgs a) {

@@ -512,9 +512,14 @@ struct tf_solver {
     bool jconst = false, cf_valid = false, reused = false;
     double cf_c = 0.0;
     uint64_t par_ver = 0, cf_ver = 0;
-    bool reuse_ok(double c) const { return jconst && cf_valid && have_jac && cf_c == c && cf_ver == par_ver; }
+    // (the same c up to a few ulp: a driver that lands on t + dt computes its step as target - t, which
+    // is dt give or take the rounding of t + dt (schemes.py:58, 217; simulation.py:215-217) -- I - cJ then
+    // differs from the factorised matrix by 1e-16 relative, the size of the factorisation's own rounding;
+    // the right-hand side is formed with the caller's dt)
+    static bool same_c(double a, double b) { return a == b || std::fabs(a - b) <= 1e-15 * std::fabs(b); }
+    bool reuse_ok(double c) const { return jconst && cf_valid && have_jac && same_c(cf_c, c) && cf_ver == par_ver; }
     bool alt_ok(double c) const {
-        return jconst && alt_allocated && meta_alt.cf_valid && have_jac && meta_alt.cf_c == c && meta_alt.cf_ver == par_ver;
+        return jconst && alt_allocated && meta_alt.cf_valid && have_jac && same_c(meta_alt.cf_c, c) && meta_alt.cf_ver == par_ver;
     }
     // the factorisation in memory is valid for another c: the next one goes to the other set
     bool wants_alt(double c) const {
