@@ -688,3 +688,48 @@ def test_neumann_python_hook():
 
 def test_adaptive_landing_reuse():
     pc.check_adaptive_landing_reuse(HIP)
+
+
+@pytest.mark.parametrize("name,N", [("M2_diff", 20011), ("kdv", 70003), ("burgers", 5003), ("bivar", 9001),
+                                    ("M1_advdiff", 300007)])
+def test_scalar_solve_in_two_launches(name, N, monkeypatch):
+    """b = mp * nvar <= 2 with the plan [level 1 | 256-node chunks | one chunk]: tfk_s_fwd / tfk_s_bwd run
+    the kernels' bodies of the six-launch solve in two launches -- the same operations, the same bits;
+    against SuperLU as well; periodic and clamped; a solve that rides with the factorisation and later ones."""
+    m, mo = pc.device_model(name, HIP), pc.oracle_model(name)
+    rng = np.random.default_rng(11)
+    for periodic in (True, False):
+        fd = corpus.synthetic_fields(name, N, seed=7, periodic=periodic, length=N * 5e-3)
+        pars = corpus.synthetic_pars(name, N, periodic)
+        n = N * m._nvar
+        rhs = rng.standard_normal(n)
+        out = {}
+        for fuse in ("1", "0"):
+            monkeypatch.setenv("TRIFLOW_S_FUSE", fuse)
+            solver = pc.bound_solver(m, fd, pars, refine=0)
+            assert len(solver.describe()["chunks"]) == 3, solver.describe()
+            solver.eval(0, with_j=True)
+            solver.factor(0.01)
+            out[fuse] = [solver.solve(rhs)[0], solver.solve(rhs[::-1].copy())[0]]
+            m._device.release()          # (the per-shape solver cache: the switch is read when a solver is made)
+        for a, b in zip(out["1"], out["0"]):
+            assert np.isfinite(a).all() and np.array_equal(a, b), (name, periodic, np.abs(a - b).max())
+        Jo = mo.J(mo.fields_template(**fd), pars)
+        xs = spla.spsolve(sps.identity(n, format="csc") - 0.01 * Jo, rhs)
+        err = np.abs(out["1"][0] - xs).max() / np.abs(xs).max()
+        assert err <= 1e-8, (name, periodic, err)
+    # the launches a Theta step of the constant-matrix model makes once its factorisation is kept
+    if name == "M2_diff":
+        monkeypatch.setenv("TRIFLOW_S_FUSE", "1")
+        _, fdc, parsc, dt, _ = corpus.config_inputs(2, 40000)
+        sch = schemes.Theta(m)
+        f, t = m.fields_template(**fdc), 0.0
+        for _ in range(3):
+            t, f = sch(t, f, dt, parsc)
+        solver = f._device_backing().stepper.solver
+        solver.timing(True); solver.timing_reset()
+        t, f = sch(t, f, dt, parsc)
+        solver.sync()
+        rep = solver.timing_report()
+        solver.timing(False)
+        assert set(rep) == {"tfk_sweep_fj_theta", "tfk_s_fwd", "tfk_s_bwd"}, rep

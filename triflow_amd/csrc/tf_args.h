@@ -112,6 +112,14 @@ struct TfBerrArgs {               // componentwise backward error of (I - cJ) x 
     const double* rhs;             // [nvar] planes
     double c;
     double* red;                   // max_i |b - Ax|_i / (|x| + |cJ||x| + |b|)_i
+    // Sampled form (the monitor of the Theta / BDF-2 steps): workgroup x of the launch takes the chunks
+    // of workgroup x * blk_stride + blk_phase of the full launch (1, 0: every workgroup).
+    int blk_stride, blk_phase;
+    // non-NULL: x holds a new state U+ = xbase + delta and the system is (I - cJ) delta = b, i.e.
+    // (I - cJ) U+ = b + (I - cJ) xbase: the error is measured on that form (magnitudes |U+| + |xbase|) --
+    // delta itself is not in memory when the back-substitution forms the new state, and U+ - xbase
+    // carries the rounding of the sum
+    const double* xbase;
 };
 
 struct TfVecArgs {                 // elementwise plane algebra
@@ -260,6 +268,16 @@ struct TfTailArgs {                // tfk_cr_tail: the last two cyclic-reduction
     TfLevelArgs lv[2];
 };
 
+// tfk_s_fwd / tfk_s_bwd: a whole solve of a model with b = mp * nvar <= 2 in two launches.  The plan is
+// [level 1 | level 2: cyclic reduction in 256-node chunks | level 3: one chunk per system]; workgroup q
+// owns chunk q of level 2, i.e. the level-1 chunks whose separators are that chunk's nodes: it walks
+// them, reduces its chunk and hands its share of level 3 on -- the workgroup of a system that arrives
+// last (`counter`, one per system, left at zero) solves level 3.  The second launch is the way back.
+struct TfScalarArgs {
+    TfLevelArgs lv[3];
+    unsigned* counter;             // [nsys]
+};
+
 struct TfTopArgs {                 // final 1-node system per ensemble member
     int nsys;
     const double* A;               // [3][b][b] planes with Ptot = nsys
@@ -314,7 +332,8 @@ enum TfKernel {
     TFK_BT_LU, TFK_BT_SPIKE, TFK_BT_RHS, TFK_BT_ASM_MAT, TFK_BT_ASM_RHS, TFK_BT_BACKSUB,
     TFK_TOP_FACTOR, TFK_TOP_SOLVE, TFK_BERR, TFK_DIFFNORM, TFK_L1_FACTOR_RHS, TFK_SWEEP_F_STAGE,
     TFK_CR_FACTOR, TFK_CR_FWD, TFK_CR_BWD, TFK_POKE, TFK_SWEEP_FJ_THETA, TFK_SWEEP_FJ_BDF2, TFK_SPMV_MON, TFK_GATHER,
-    TFK_SWEEP_F_STAGE_RHS, TFK_L1_FWD2, TFK_L1_BACKSUB_U, TFK_CR_TAIL, TFK_L1_FWD2_BACKSUB, TFK_TINY_FACTOR, TFK_TINY_SOLVE, TFK_COUNT
+    TFK_SWEEP_F_STAGE_RHS, TFK_L1_FWD2, TFK_L1_BACKSUB_U, TFK_CR_TAIL, TFK_L1_FWD2_BACKSUB, TFK_TINY_FACTOR, TFK_TINY_SOLVE,
+    TFK_S_FWD, TFK_S_BWD, TFK_COUNT
 };
 #define TF_KERNEL_NAMES { \
     "tfk_sweep_f", "tfk_sweep_fj", "tfk_spmv", "tfk_vec", "tfk_vec_maxabs", "tfk_perm", "tfk_dirichlet", \
@@ -323,4 +342,4 @@ enum TfKernel {
     "tfk_top_factor", "tfk_top_solve", "tfk_berr", "tfk_diffnorm", "tfk_l1_factor_rhs", "tfk_sweep_f_stage", \
     "tfk_cr_factor", "tfk_cr_fwd", "tfk_cr_bwd", "tfk_poke", "tfk_sweep_fj_theta", "tfk_sweep_fj_bdf2", \
     "tfk_spmv_mon", "tfk_gather", "tfk_sweep_f_stage_rhs", "tfk_l1_fwd2", "tfk_l1_backsub_u", "tfk_cr_tail", \
-    "tfk_l1_fwd2_backsub", "tfk_tiny_factor", "tfk_tiny_solve" }
+    "tfk_l1_fwd2_backsub", "tfk_tiny_factor", "tfk_tiny_solve", "tfk_s_fwd", "tfk_s_bwd" }

@@ -335,8 +335,11 @@ TF_DEVICE void tfk_crs_fwd(const TfLevelArgs& a, int chunk, int tid) {
     }
 }
 
+// store_prev: the solution of the separator above (a node of the previous chunk, known from the next
+// level) is written into this level's x as well -- a caller that goes on to the level below inside
+// the same workgroup (tfk_s_bwd) finds both separators of its first chunk without another workgroup
 template <int BB, int NT>
-TF_DEVICE void tfk_crs_bwd(const TfLevelArgs& a, int chunk, int tid) {
+TF_DEVICE void tfk_crs_bwd(const TfLevelArgs& a, int chunk, int tid, bool store_prev = false) {
     typedef TfCrs<BB> C;
     constexpr int NPOS = C::NPOS, B2 = BB * BB;
     const TfLayout& L = a.L;
@@ -355,6 +358,7 @@ TF_DEVICE void tfk_crs_bwd(const TfLevelArgs& a, int chunk, int tid) {
         sX[pe * BB + r] = xs;
         a.x[(ch.nbase + ch.node(pe)) * BB + r] = xs;
         sX[r] = ch.has_prev ? a.xnext[((int64_t)ch.e * a.Lnext.N + ch.pprev) * BB + r] : 0.0;
+        if (store_prev && ch.has_prev) a.x[(ch.nbase + ch.gprev) * BB + r] = sX[r];
     }
     TF_BARRIER();
     int s = 1;

@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(256) tfk_vec_maxabs(TfVecArgs a) {
 }
 
 __global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_berr(TfBerrArgs a) {
-    const double m = tfk_berr_body(a, TF_GID, blockIdx.y);
+    const double m = tfk_berr_body(a, (int)((blockIdx.x * a.blk_stride + a.blk_phase) * blockDim.x + threadIdx.x), blockIdx.y);
     unsigned long long bits = (unsigned long long)__double_as_longlong(m);
     if (m != m) bits = 0x7ff8000000000000ull;
 #pragma unroll
@@ -361,6 +361,67 @@ __global__ void __launch_bounds__(TF_CR_BLOCK) tfk_cr_bwd(TfLevelArgs a) {
     else if constexpr (TF_B2 <= 8) tfk_cr_bwd_coop<TF_B2>(a);
 }
 // the last two levels of a solve: one workgroup per system (3 <= b <= 8; the host only launches it there)
+// ---- b <= 2: a solve in two launches (TfScalarArgs).  As six launches (walks, two forward levels, two
+// backward levels, back-substitution) config 2 spent 41 us in them for 50 MB of traffic: every launch
+// is a round trip to memory for what the previous one left and 4-14 us of one wavefront's latency.
+// Here the workgroup that owns a level-2 chunk also runs the level-1 walks that feed it (threads
+// 0-255: down walks of its <= 256 level-1 chunks, threads 256-511: the up walks that end below its
+// separators, i.e. of the chunks one further on), so the level-2 right-hand side never waits for
+// another workgroup; the last workgroup of a system to finish solves level 3 (no waiting: the
+// others simply end).  tfk_s_bwd: level 2 backwards, then the level-1 back-substitution of the same
+// chunks -- the separator above its first chunk is a level-3 node, known before the launch.
+__global__ void __launch_bounds__(512) tfk_s_fwd(TfScalarArgs t) {
+    if constexpr (TF_B2 <= 2) {
+        const TfLevelArgs& l1 = t.lv[0];
+        const TfLevelArgs& l2 = t.lv[1];
+        const int tid = threadIdx.x;
+        const TfCrChunk<TF_B2> ch(l2.L, (int)blockIdx.x);
+        const int P1 = l1.L.P;
+        if (tid < 256) {
+            if (tid < ch.len) tfk_chunk_body<TfRowsL1, +1, false, false, true>(l1, ch.e * P1 + ch.start + tid);
+        } else if (tid - 256 < ch.len) {
+            int c = ch.start + tid - 256 + 1;                       // the chunk whose up walk ends below node c - 1
+            if (c == P1) c = l1.L.periodic ? 0 : -1;
+            if (c >= 0) tfk_chunk_body<TfRowsL1, -1, false, false, false>(l1, ch.e * P1 + c);
+        }
+        // the level-2 right-hand side records of this chunk's nodes were written by this workgroup
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        tfk_crs_fwd<TF_B2, 512>(l2, (int)blockIdx.x, tid);
+        // ---- the workgroup of this system that arrives last solves level 3
+        __shared__ int last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned seen = __hip_atomic_fetch_add(t.counter + ch.e, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int is_last = seen == (unsigned)l2.L.P - 1u;
+            if (is_last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(t.counter + ch.e, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            last = is_last;
+        }
+        __syncthreads();
+        if (last) tfk_crs_fwd<TF_B2, 512>(t.lv[2], ch.e, tid);
+    }
+}
+__global__ void __launch_bounds__(512) tfk_s_bwd(TfScalarArgs t) {
+    if constexpr (TF_B2 <= 2) {
+        const TfLevelArgs& l1 = t.lv[0];
+        const TfLevelArgs& l2 = t.lv[1];
+        const int tid = threadIdx.x;
+        const TfCrChunk<TF_B2> ch(l2.L, (int)blockIdx.x);
+        tfk_crs_bwd<TF_B2, 512>(l2, (int)blockIdx.x, tid, true);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (tid < ch.len) tfk_backsub_body<TfRowsL1, true>(l1, ch.e * l1.L.P + ch.start + tid);
+    }
+}
 __global__ void __launch_bounds__(64 * TF_CR_TAIL_WAVES) tfk_cr_tail(TfTailArgs t) {
     if constexpr (TF_B2 >= 3 && TF_B2 <= TF_CR_TAIL_MAXB) tfk_cr_tail_coop<TF_B2>(t);
 }

@@ -391,16 +391,20 @@ TF_DEVICE double tfk_berr_body(const TfBerrArgs& a, int pg, int seg) {
     const int len = tf_len(L, p);
     const int i0 = seg * TF_SEG;
     if (i0 >= len) return 0.0;
-    auto ld = [&](int v, int ii) -> double {
-        const double* plane = a.x + (int64_t)v * L.plane;
-        if (ii >= 0 && ii < len) return plane[tf_idx(L, pg, ii)];
-        return plane[tf_nbr(L, e, p, len, 0, ii)];
+    const bool based = a.xbase != nullptr;
+    // value and magnitude of the unknown at (variable v, node ii of the chunk, ghost nodes included)
+    auto ld = [&](int v, int ii, double& val, double& mag) {
+        const int64_t at = (ii >= 0 && ii < len) ? tf_idx(L, pg, ii) : tf_nbr(L, e, p, len, 0, ii);
+        const double xv = a.x[(int64_t)v * L.plane + at];
+        const double xb = based ? a.xbase[(int64_t)v * L.plane + at] : 0.0;
+        val = xv - xb;
+        mag = based ? tf_abs(xv) + tf_abs(xb) : tf_abs(xv);
     };
-    double w[TF_NVAR][TF_W];
+    double w[TF_NVAR][TF_W], wm[TF_NVAR][TF_W];
 #pragma unroll
     for (int v = 0; v < TF_NVAR; ++v)
 #pragma unroll
-        for (int o = 1; o < TF_W; ++o) w[v][o] = ld(v, i0 - TF_MP + o - 1);
+        for (int o = 1; o < TF_W; ++o) ld(v, i0 - TF_MP + o - 1, w[v][o], wm[v][o]);
     TfJUniform ju;
     ju.init(a.parsca, a.dx, L.nsys, e);
     double worst = 0.0;
@@ -411,8 +415,8 @@ TF_DEVICE double tfk_berr_body(const TfBerrArgs& a, int pg, int seg) {
 #pragma unroll
             for (int v = 0; v < TF_NVAR; ++v) {
 #pragma unroll
-                for (int o = 0; o < TF_W - 1; ++o) w[v][o] = w[v][o + 1];
-                w[v][TF_W - 1] = ld(v, i + TF_MP);
+                for (int o = 0; o < TF_W - 1; ++o) { w[v][o] = w[v][o + 1]; wm[v][o] = wm[v][o + 1]; }
+                ld(v, i + TF_MP, w[v][TF_W - 1], wm[v][TF_W - 1]);
             }
             const int64_t s = tf_idx(L, pg, i);
             double acc[TF_NVAR], mag[TF_NVAR];
@@ -423,16 +427,14 @@ TF_DEVICE double tfk_berr_body(const TfBerrArgs& a, int pg, int seg) {
 #pragma unroll
             for (int k = 0; k < TF_NNZ; ++k) {
                 const double jv = a.c * jr[k];
-                const double wv = w[tf_pat_var[k]][tf_pat_off[k] + TF_MP];
-                acc[tf_pat_eq[k]] = acc[tf_pat_eq[k]] + jv * wv;
-                mag[tf_pat_eq[k]] = mag[tf_pat_eq[k]] + tf_abs(jv) * tf_abs(wv);
+                acc[tf_pat_eq[k]] = acc[tf_pat_eq[k]] + jv * w[tf_pat_var[k]][tf_pat_off[k] + TF_MP];
+                mag[tf_pat_eq[k]] = mag[tf_pat_eq[k]] + tf_abs(jv) * wm[tf_pat_var[k]][tf_pat_off[k] + TF_MP];
             }
 #pragma unroll
             for (int v = 0; v < TF_NVAR; ++v) {
                 const double b = a.rhs[(int64_t)v * L.plane + s];
-                const double xv = w[v][TF_MP];
-                const double num = tf_abs((b - xv) + acc[v]);
-                const double den = tf_abs(xv) + mag[v] + tf_abs(b);
+                const double num = tf_abs((b - w[v][TF_MP]) + acc[v]);
+                const double den = wm[v][TF_MP] + mag[v] + tf_abs(b);
                 const double q = num == 0.0 ? 0.0 : num / den;
                 worst = (q > worst || q != q) ? q : worst;
             }

@@ -330,6 +330,7 @@ struct tf_solver {
         if (poke_buf) tfb::dev_free(poke_buf);
         if (csc_map) tfb::dev_free(csc_map);
         if (status) tfb::dev_free(status);
+        if (sfuse_counter) tfb::dev_free(sfuse_counter);
         if (dir_var) tfb::dev_free(dir_var);
         if (dir_node) tfb::dev_free(dir_node);
         delete fallback;
@@ -794,6 +795,12 @@ struct tf_solver {
     // inside its forward / factor kernel -- a cyclic-reduction level that folds the top block
     // in; 2: the two last levels by tfk_cr_tail)
     void backsub_chain(const double* rhs1, double* x1, int skip) {
+        if (skip == 1 && scalar_fused_ok()) {
+            TfScalarArgs t = scalar_args(rhs1, x1);
+            upd_req_on = false;
+            launch(TFK_S_BWD, (unsigned)t.lv[1].L.Ptot, 1, 512, &t, sizeof(t));
+            return;
+        }
         for (size_t l = levels.size() - (size_t)skip; l-- > 0;) {
             TfLevelArgs a = level_args(l, rhs1, x1);
             if (l == 0) {
@@ -818,6 +825,21 @@ struct tf_solver {
             else launch(TFK_BT_BACKSUB, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
         }
     }
+    // b = mp * nvar <= 2 with the plan [level 1 | 256-node cyclic-reduction chunks | one chunk]: a solve
+    // is two launches (tfk_s_fwd / tfk_s_bwd, TfScalarArgs) instead of six
+    bool s_fuse = true;            // (TRIFLOW_S_FUSE=0: A/B runs, tests)
+    unsigned* sfuse_counter = nullptr;
+    bool scalar_fused_ok() const {
+        return s_fuse && tfb::is_device_build() && !tiny && top.B <= 2 && levels.size() == 3 && levels[1]->cr &&
+               levels[2]->cr && levels[2]->L.P == 1 && fold_top() && fuse_asm_ok() && !l1_respike;
+    }
+    TfScalarArgs scalar_args(const double* rhs1, double* x1) {
+        TfScalarArgs t;
+        for (size_t l = 0; l < 3; ++l) t.lv[l] = level_args(l, rhs1, x1);
+        if (!sfuse_counter) sfuse_counter = (unsigned*)tfb::dev_alloc((size_t)nsys * sizeof(unsigned));
+        t.counter = sfuse_counter;
+        return t;
+    }
     // The two last levels of a solve go in one launch (tfk_cr_tail) when both are cyclic-reduction
     // levels of 3 <= b <= 6 and the first of them has at most 8 chunks per system
     bool cr_tail = true;           // (TRIFLOW_CR_TAIL=0: A/B runs)
@@ -830,6 +852,12 @@ struct tf_solver {
         if (tiny) {
             TfTinyArgs t = tiny_args(rhs1, x1);
             launch(TFK_TINY_SOLVE, cdiv(nsys, 64), 1, 64, &t, sizeof(t));
+            return;
+        }
+        if (scalar_fused_ok()) {
+            TfScalarArgs t = scalar_args(rhs1, x1);
+            launch(TFK_S_FWD, (unsigned)t.lv[1].L.Ptot, 1, 512, &t, sizeof(t));
+            backsub_chain(rhs1, x1, 1);
             return;
         }
         const bool tail = tail_ok();
@@ -867,13 +895,39 @@ struct tf_solver {
         ++n_checks;
         tfb::memset0(red.p, sizeof(double), stream);
         TfBerrArgs a;
+        std::memset(&a, 0, sizeof(a));
         a.L = L1; a.Jv = Jv.p; a.x = x1; a.rhs = rhs1; a.c = factor_c; a.red = red.p;
-        a.parsca = parsca.p; a.dx = dx.p;
+        a.parsca = parsca.p; a.dx = dx.p; a.blk_stride = 1;
         unsigned gx = sweep_gx(), gy = cdiv(L1.M, spec.seg);
         launch(TFK_BERR, gx, gy, spec.sweep_block, &a, sizeof(a));
         double h = 0;
         tfb::d2h(&h, red.p, sizeof(h), stream);
         return h;
+    }
+    // The monitor of the Theta and BDF-2 steps (the Rosenbrock steps have theirs inside the J @ v pass
+    // of stage 1, tfk_spmv_mon): between two synchronising checks every new factorisation has the same
+    // backward error measured on one workgroup in TF_MON_STRIDE of the full pass (a rotating sixteenth of
+    // the chunks: ~1 % of a step of config 5), with no host wait -- the maximum goes to red[4] and is
+    // looked at by the next synchronising call, like the Rosenbrock monitor's.  A factorisation that
+    // lost accuracy did so because of what the matrix is like, i.e. in many chunks at once.
+    // xbase: the state the step started from, when x1 is the new state of a step whose solve leaves
+    // U + delta instead of delta (TfBerrArgs::xbase).
+    static constexpr unsigned TF_MON_STRIDE = 16;
+    unsigned mon_phase = 0;
+    bool sampled_monitor_due() const {
+        return refine < 0 && !reused && !delegated && !tiny && have_factor && !(refine == -1 && check_now);
+    }
+    void monitor_sampled(const double* rhs1, const double* x1, const double* xbase) {
+        TfBerrArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.L = L1; a.Jv = Jv.p; a.x = x1; a.rhs = rhs1; a.c = factor_c; a.red = red.p + 4;
+        a.parsca = parsca.p; a.dx = dx.p; a.xbase = xbase;
+        const unsigned gx = sweep_gx(), gy = cdiv(L1.M, spec.seg);
+        const unsigned stride = gx >= 4 * TF_MON_STRIDE ? TF_MON_STRIDE : 1;     // (small grids: the whole pass is a few us)
+        a.blk_stride = (int)stride; a.blk_phase = (int)(mon_phase++ % stride);
+        const unsigned n = (gx - (unsigned)a.blk_phase + stride - 1) / stride;
+        launch(TFK_BERR, n, gy, spec.sweep_block, &a, sizeof(a));
+        monitored = true;
     }
     // x = (I - c J)^-1 rhs.  refine > 0: that many refinement sweeps; refine == -1
     // (default): the first solve after every factorisation measures the backward
@@ -1107,6 +1161,7 @@ tf_solver* make_solver(tf_model* model, int64_t N, int32_t nsys, int32_t periodi
     if (const char* v = getenv("TRIFLOW_GRAPHS")) s->graphs_on = tfb::graphs_supported() && atoi(v) != 0;
     if (const char* v = getenv("TRIFLOW_FUSE_STAGE")) s->fuse_stage = atoi(v) != 0;      // A/B runs
     if (const char* v = getenv("TRIFLOW_CR_TAIL")) s->cr_tail = atoi(v) != 0;
+    if (const char* v = getenv("TRIFLOW_S_FUSE")) s->s_fuse = atoi(v) != 0;
     if (const char* v = getenv("TRIFLOW_L1_FUSE_BACKSUB")) s->l1_fuse_backsub = atoi(v) != 0;
     if (const char* v = getenv("TRIFLOW_TWO_FACTORS")) s->two_slots = atoi(v) != 0;
     if (const char* v = getenv("TRIFLOW_L1_FUSE_ASM")) s->l1_fuse_asm = atoi(v) != 0;
@@ -1190,6 +1245,7 @@ tf_solver* make_solver(tf_model* model, int64_t N, int32_t nsys, int32_t periodi
     for (int i = 0; i < TF_MAX_TERMS; ++i) s->K[i].alloc(i < 6 ? (size_t)sp.nvar * plane : 1, tot);
     s->red.alloc(8, tot);
     s->status = (int*)tfb::dev_alloc(sizeof(int));
+    if (b2 <= 2) s->sfuse_counter = (unsigned*)tfb::dev_alloc((size_t)nsys * sizeof(unsigned));   // (TfScalarArgs)
     for (size_t l = 0; l < s->levels.size(); ++l) s->levels[l]->alloc(l, nsys, s->l1_respike, tot);
     s->top.alloc_top(b2, nsys, tot);
     s->topAinv.alloc((size_t)b2 * b2 * nsys, tot);
@@ -1545,6 +1601,7 @@ void step_theta(tf_solver* s, int32_t src, int32_t dst, double dt, double theta)
     const double* Uin = s->stage_input(src, U);                    // copy + hook only when there is a hook
     s->sweep_theta(Uin, dt, theta, s->Wrhs.p);                     // F, J, dt*(F - (theta*J)@U) + U
     s->factor_step(theta * dt, s->Wrhs.p, U);
+    if (s->sampled_monitor_due()) s->monitor_sampled(s->Wrhs.p, U, nullptr);      // (I - theta dt J) U+ = B
     s->apply_dirichlet(U, true);
     s->mark_hooked(dst);
 }
@@ -1754,7 +1811,13 @@ void step_bdf2(tf_solver* s, int32_t src, int32_t dst, double dt, tf_solver::Bdf
     s->request_update(U, Uin, nullptr, 1.0, 0.0, 1);               // (1.0 * x == x: the sum of TF_VEC_ADD)
     s->factor_step(two_step ? (2.0 / 3.0) * dt : dt, s->Wrhs.p, s->Wdel.p);
     const double* ys[2] = {Uin, s->Wdel.p};
-    if (!s->take_update_done()) s->vec(TF_VEC_ADD, U, nullptr, 2, ys, nullptr);
+    const bool in_walk = s->take_update_done();
+    if (!in_walk) s->vec(TF_VEC_ADD, U, nullptr, 2, ys, nullptr);
+    if (s->sampled_monitor_due()) {
+        // (the solve left U + delta: measured on the state form unless the input was hooked into dst itself)
+        if (!in_walk) s->monitor_sampled(s->Wrhs.p, s->Wdel.p, nullptr);
+        else if (Uin != U) s->monitor_sampled(s->Wrhs.p, U, Uin);
+    }
     s->apply_dirichlet(U, true);
     s->mark_hooked(dst);
 }
