@@ -14,6 +14,7 @@ broadcasts the parameter table once over RCCL.  Weak scaling: the per-GPU work
 (--members-per-gpu members of 1e6 nodes) is fixed as N grows.
 """
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -113,6 +114,39 @@ def _cpu_sample(job):
 CPU_STEPS = 3
 
 
+def _cpu_worker(job, conn):
+    try:
+        conn.send(_cpu_sample(job))
+    finally:
+        conn.close()
+
+
+def _run_cpu_workers(job, n):
+    """`n` oracle processes on the same job; returns (results, exit codes of the workers that died).
+    Processes of their own: SciPy's SuperLU dies (SIGSEGV inside gssv, 32-bit work-array sizes) on the
+    2e7 unknowns of config 5 at full size -- the reference's own solver call, schemes.py:557 -- and that
+    must not take the device's result down with it; the exit code says what happened."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    procs = []
+    for _ in range(n):
+        recv, send = ctx.Pipe(duplex=False)
+        p = ctx.Process(target=_cpu_worker, args=(job, send))
+        p.start()
+        send.close()
+        procs.append((p, recv))
+    res, died = [], []
+    for p, recv in procs:
+        try:
+            res.append(recv.recv())              # (before join: a large state must be drained first)
+        except EOFError:
+            pass
+        p.join()
+        if p.exitcode != 0:
+            died.append(p.exitcode)
+    return res, died
+
+
 def cpu_baseline(cfg, N, scheme_name, fair=False, workers=1, want_state=False):
     """The reference's algorithm (oracle = NumPy/SciPy port of the numpy-compiler
     path + SuperLU) on this box's host cores, full size.  The algorithm is single
@@ -127,24 +161,27 @@ def cpu_baseline(cfg, N, scheme_name, fair=False, workers=1, want_state=False):
     # The checker runs in processes of its own: SciPy's SuperLU dies (SIGSEGV inside gssv, 32-bit
     # work-array sizes) on the 2e7 unknowns of config 5 at full size -- the reference's own solver
     # call, schemes.py:557 -- and that must not take the device's result down with it.
-    import multiprocessing as mp
-    from concurrent.futures import ProcessPoolExecutor
-    from concurrent.futures.process import BrokenProcessPool
-    try:
-        with ProcessPoolExecutor(max(workers, 1), mp_context=mp.get_context("spawn")) as pool:
-            res = list(pool.map(_cpu_sample, [job] * max(workers, 1)))
-    except BrokenProcessPool:
-        if N >= 2000:
-            # the cost of the reference's algorithm is linear in N: half the nodes, half the rate
-            half = cpu_baseline(cfg, N // 2, scheme_name, fair=fair, workers=workers)
+    res, died = _run_cpu_workers(job, max(workers, 1))
+    if died:
+        import signal
+        segv = all(code == -signal.SIGSEGV for code in died)
+        if segv and N >= 2000:
+            # SuperLU cannot factorise a system of this size; the cost of the reference's algorithm is
+            # linear in N: half the nodes, half the rate (the state of that run is handed back so that
+            # the parity check can be made at that size)
+            half = cpu_baseline(cfg, N // 2, scheme_name, fair=fair, workers=workers, want_state=want_state)
+            half, half_state = half if want_state else (half, None)
             if half.get("value"):
-                half.update(value=half["value"] / 2.0, extrapolated_from_nodes=N // 2,
-                            sample="the oracle process died at N=%d (SciPy SuperLU cannot factorise a system of "
-                                   "this size: SIGSEGV inside gssv, the reference's own solver call); measured at "
-                                   "N=%d and halved (the algorithm is linear in N): %s" % (N, N // 2, half["sample"]))
-            return (half, None) if want_state else half
-        out = dict(value=None, unit="steps/s", cores=max(workers, 1), kind="port",
-                   sample="%d %s steps of the same workload (N=%d): the oracle process died" % (nsteps, scheme_name, N))
+                half.update(value=half["value"] / 2.0, extrapolated_from_nodes=half.get("extrapolated_from_nodes", N // 2),
+                            worker_exit="SIGSEGV",
+                            sample="the oracle process died with SIGSEGV at N=%d (SciPy SuperLU cannot factorise a system "
+                                   "of this size: inside gssv, the reference's own solver call); measured at N=%d and "
+                                   "halved (the algorithm is linear in N): %s" % (N, N // 2, half["sample"]))
+            return (half, half_state) if want_state else half
+        how = ", ".join(sorted(set("exit code %d" % c if c >= 0 else "signal %s" % signal.Signals(-c).name for c in died)))
+        out = dict(value=None, unit="steps/s", cores=max(workers, 1), kind="port", worker_exit=how,
+                   sample="%d %s steps of the same workload (N=%d): the oracle process ended with %s "
+                          "(nothing extrapolated)" % (nsteps, scheme_name, N, how))
         return (out, None) if want_state else out
     el = max(r[0] for r in res)                     # slowest member, stepping only
     if workers <= 1:
@@ -250,10 +287,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")          # (torch.distributed.run sets both)
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world,
+            dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(hours=1),
                                     device_id=torch.device("cuda", device_index))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(hours=1))
 
     from triflow_amd import Model, workloads
     from triflow_amd.ensemble import Ensemble, broadcast_table, shard_members
@@ -494,10 +531,21 @@ def main():
             # state after its timed steps pins the device state of this very run
             check = args.members_per_gpu == 1
             out["cpu_baseline"], ref_state = cpu_baseline(args.config, N, scheme, want_state=True)
+            n_ref = out["cpu_baseline"].get("extrapolated_from_nodes", N)
             if check and ref_state is None:
-                out["parity"] = None                  # (no oracle state at this size: see cpu_baseline.sample)
+                out["parity"] = {"skipped": "no oracle state: " + out["cpu_baseline"]["sample"]}
             elif check:
-                out["parity"] = device_parity(ens, dt, CPU_STEPS, ref_state)
+                pens = ens
+                if n_ref != N:
+                    # the oracle only ran at n_ref nodes (see cpu_baseline.sample): the device takes the
+                    # same steps at that size
+                    _, xh, fh, ph, _, _ = build_problem(args.config, n_ref, table[mine])
+                    pens = Ensemble(model, xh, fh, ph, bool(ph["periodic"]), scheme=scheme, device=device_index,
+                                    hook=config_hook(args.config), nstate=4 if scheme == "BDF2" else 3)
+                out["parity"] = device_parity(pens, dt, CPU_STEPS, ref_state)
+                out["parity"]["nodes"] = n_ref
+                if pens is not ens:
+                    pens.close()
                 bound = PARITY_BOUND[args.config]
                 out["parity"]["bound"] = bound
                 if not out["parity"]["rel_err"] <= bound:
@@ -511,7 +559,7 @@ def main():
         if parity_failed:
             raise SystemExit(parity_failed)
     if multi:
-        dist.barrier()            # (rank 0 may still have been timing the CPU baseline)
+        dist.barrier()            # (rank 0 may still have been timing the CPU baseline: the group's timeout allows for it)
         dist.destroy_process_group()
 
 

@@ -101,8 +101,7 @@ void launch(Module*, int kernel, unsigned gx, unsigned gy, unsigned block,
     case TFK_BERR: { const auto& a = *(const TfBerrArgs*)args;
         double m = *a.red;
         for (unsigned y = 0; y < gy; ++y) for (int64_t t = 0; t < nthreads; ++t) {
-            const int64_t pg = ((t / block) * a.blk_stride + a.blk_phase) * block + t % block;
-            double v = tfk_berr_body(a, (int)pg, (int)y); m = (v > m || v != v) ? v : m; }
+            double v = tfk_berr_body(a, (int)t, (int)y); m = (v > m || v != v) ? v : m; }
         *a.red = m; } break;
     case TFK_DIFFNORM: { const auto& a = *(const TfNormArgs*)args;
         for (unsigned y = 0; y < gy; ++y) for (unsigned b = 0; b < gx; ++b)

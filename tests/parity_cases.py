@@ -1224,6 +1224,53 @@ def check_row_monitor(backend):
     assert worst < 1e-6, worst
 
 
+def check_theta_bdf2_monitor(backend):
+    """Theta and BDF-2 steps have no J @ v pass to ride on: between two synchronising checks every new
+    factorisation is probed at one node of every level-1 chunk (a different one in every step) by a
+    launch that nobody waits for (tf_solver::monitor_sampled).  (i) Healthy runs read rounding level,
+    also on the state form of a BDF-2 step whose solve leaves U + delta (config 5 with its hook).
+    (ii) A factorisation that loses accuracy between two checks -- the dispersive model on 4-node
+    chunks, explicit checks switched off -- is reported by the next synchronising call."""
+    from triflow_amd.ensemble import Ensemble
+    for cfg, sch, N, hook in ((5, "BDF2", 4003, DEVICE_HOOKS["cfg5"]), (5, "Theta", 2001, None), (3, "Theta", 3000, None)):
+        name, fd, pars, dt, _ = corpus.config_inputs(cfg, N)
+        m = device_model(name, backend)
+        fields = {k: v[None, :] for k, v in fd.items() if k != "x"}
+        ens = Ensemble(m, fd["x"], fields, pars, bool(pars["periodic"]), scheme=sch, hook=hook, nstate=4, refine=-2)
+        worst = 0.0
+        for _ in range(12):
+            ens.step(dt)
+            worst = max(worst, ens.solver.monitor_error())
+        ens.sync()
+        assert 0.0 <= worst < 1e-11, (cfg, sch, worst)
+        if cfg == 5:
+            assert worst > 0.0                          # (the probe did measure something)
+        ens.close()
+    N = 203
+    x = np.linspace(0, N * 5e-3, N, endpoint=False)
+    mk = device_model("kdv", backend)
+    U = (1.0 + 0.3 * np.cos(2 * np.pi * x / x[-1]))[None, :]
+    for sch in ("Theta", "BDF2"):
+        ens = Ensemble(mk, x, dict(U=U), dict(periodic=True), True, scheme=sch, nstate=4, m1=4, m_upper=2, refine=-2)
+        for _ in range(4):
+            ens.step(0.1)
+        assert ens.solver.monitor_error() > 1e-6, sch
+        raised = False
+        try:
+            ens.sync()
+        except RuntimeError as ex:
+            raised = "lost accuracy" in str(ex)
+        assert raised, sch
+        # default mode (explicit checks + the probe in between): the checks are spaced out, the probe is not
+        ens = Ensemble(mk, x, dict(U=U), dict(periodic=True), True, scheme=sch, nstate=4, refine=-2)
+        for _ in range(4):
+            ens.step(0.1)
+        worst = ens.solver.monitor_error()
+        ens.sync()
+        assert worst < 1e-6, (sch, worst)
+        ens.close()
+
+
 def check_ensemble_equals_single_members(backend, N=3000, nsys=3, steps=3, exact=True, **opts):
     """nsys members stepped together in one solver (per-member scalar parameters and
     initial conditions) give, member by member, the bits of nsys separate single-member

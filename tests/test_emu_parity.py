@@ -185,3 +185,7 @@ def test_neumann_python_hook(backend):
 
 def test_adaptive_landing_reuse(backend):
     pc.check_adaptive_landing_reuse(backend)
+
+
+def test_theta_bdf2_monitor(backend):
+    pc.check_theta_bdf2_monitor(backend)

@@ -53,7 +53,6 @@ _TU_HEAD = ('#include <hip/hip_runtime.h>\n'
             '#define TF_DEVICE __device__ __forceinline__\n'
             '%s'
             '#include "tf_math.h"\n')
-_NT_STORE = '#define TF_STORE_STREAM(ptr, val) __builtin_nontemporal_store((val), (ptr))\n'
 
 _TU_TAIL = '#include "tf_kernels.h"\n#include "tf_entry_hip.h"\n'
 
@@ -204,10 +203,7 @@ def build_code_object(model, parvec_mask=0, seg=None, sweep_block=None):
     sweep_block = sweep_block or int(os.environ.get("TRIFLOW_SWEEP_BLOCK", "256"))
     body, spec = codegen.lower_model(model, parvec_mask=parvec_mask, seg=seg,
                                      sweep_block=sweep_block)
-    nt = int(os.environ.get("TRIFLOW_SWEEP_NT", "0"))
-    waves = int(os.environ.get("TRIFLOW_SWEEP_WAVES", "0"))
-    knobs = (_NT_STORE if nt else "") + ("#define TF_SWEEP_WAVES %d\n" % waves if waves else "")
-    source = _TU_HEAD % knobs + body + _TU_TAIL
+    source = _TU_HEAD % "" + body + _TU_TAIL
     tag = codegen.source_hash(source, _skeleton_stamp(), " ".join(HIPCC_FLAGS), hipcc_version(), os.environ.get("TRIFLOW_SPILL_GATE", "kernel"), "elf")
     os.makedirs(CACHE_DIR, exist_ok=True)
     hsaco = os.path.join(CACHE_DIR, "model_%s.hsaco" % tag)
@@ -217,23 +213,28 @@ def build_code_object(model, parvec_mask=0, seg=None, sweep_block=None):
         # code object.  Every file of the cache still appears by rename, never half written, so a
         # file system without working locks costs duplicate compilations, not a torn file.
         lock_path = hsaco + ".lock"
-        with open(lock_path, "w") as lock:
-            try:
-                fcntl.flock(lock, fcntl.LOCK_EX)
-            except OSError:
-                pass
-            try:
-                if not os.path.exists(hsaco):
-                    _compile_code_object(model, source, tag, hsaco)
-            finally:
+        try:
+            with open(lock_path, "w") as lock:
                 try:
-                    fcntl.flock(lock, fcntl.LOCK_UN)
+                    fcntl.flock(lock, fcntl.LOCK_EX)
                 except OSError:
                     pass
-        try:
-            os.remove(lock_path)
-        except OSError:
-            pass
+                try:
+                    if not os.path.exists(hsaco):
+                        _compile_code_object(model, source, tag, hsaco)
+                finally:
+                    try:
+                        fcntl.flock(lock, fcntl.LOCK_UN)
+                    except OSError:
+                        pass
+        finally:
+            # (also after a failed or interrupted build: nothing of it stays in the cache)
+            for leftover in [lock_path] + [os.path.join(CACHE_DIR, n) for n in os.listdir(CACHE_DIR)
+                                            if n.endswith(".%d.tmp" % os.getpid())]:
+                try:
+                    os.remove(leftover)
+                except OSError:
+                    pass
     return hsaco, spec
 
 

@@ -112,9 +112,10 @@ struct TfBerrArgs {               // componentwise backward error of (I - cJ) x 
     const double* rhs;             // [nvar] planes
     double c;
     double* red;                   // max_i |b - Ax|_i / (|x| + |cJ||x| + |b|)_i
-    // Sampled form (the monitor of the Theta / BDF-2 steps): workgroup x of the launch takes the chunks
-    // of workgroup x * blk_stride + blk_phase of the full launch (1, 0: every workgroup).
-    int blk_stride, blk_phase;
+    // Sampled form (the monitor of the Theta / BDF-2 steps), one_node >= 0: a thread looks at ONE node of
+    // its chunk, node one_node modulo the chunk's length (grid.y = 1); -1: every node of segment grid.y
+    int one_node;
+    int reserved_;
     // non-NULL: x holds a new state U+ = xbase + delta and the system is (I - cJ) delta = b, i.e.
     // (I - cJ) U+ = b + (I - cJ) xbase: the error is measured on that form (magnitudes |U+| + |xbase|) --
     // delta itself is not in memory when the back-substitution forms the new state, and U+ - xbase

@@ -228,18 +228,28 @@ TF_DEVICE void tfk_crs_factor(const TfLevelArgs& a, int chunk, int tid) {
     if (!ok) *a.status = 1;
 }
 
+// the stored reduction of a chunk's nodes into LDS (what tfk_crs_fwd / tfk_crs_bwd start with)
 template <int BB, int NT>
-TF_DEVICE void tfk_crs_fwd(const TfLevelArgs& a, int chunk, int tid) {
+TF_DEVICE void tfk_crs_stage(const TfLevelArgs& a, int chunk, int tid, double* sF) {
+    const TfCrChunk<BB> ch(a.L, chunk);
+    const double* src = a.crf + (ch.nbase + ch.start) * 5 * BB * BB;
+    for (int i = tid; i < ch.len * 5 * BB * BB; i += NT) sF[5 * BB * BB + i] = src[i];
+}
+
+// STAGED: the caller has put the stored reduction into `sF` already (tfk_crs_stage: a kernel that
+// walks level 1 first requests it before the walks, tfk_s_fwd)
+template <int BB, int NT, bool STAGED = false>
+TF_DEVICE void tfk_crs_fwd(const TfLevelArgs& a, int chunk, int tid, double* sF_staged = nullptr) {
     typedef TfCrs<BB> C;
     constexpr int NPOS = C::NPOS, B2 = BB * BB;
     const TfLayout& L = a.L;
     const TfCrChunk<BB> ch(L, chunk);
     const int mI = ch.mI, pe = ch.pe, len = ch.len;
-    TF_LDS double sF[NPOS * 5 * B2];             // stored reduction of the chunk's nodes
+    TF_LDS double sF_own[STAGED ? 1 : NPOS * 5 * B2];             // stored reduction of the chunk's nodes
     TF_LDS double sY[NPOS * BB], sZ[NPOS * BB];
+    double* const sF = STAGED ? sF_staged : sF_own;
     {
-        const double* src = a.crf + (ch.nbase + ch.start) * 5 * B2;
-        for (int i = tid; i < len * 5 * B2; i += NT) sF[5 * B2 + i] = src[i];
+        if (!STAGED) tfk_crs_stage<BB, NT>(a, chunk, tid, sF);
         const double* ys = a.rhs + (ch.nbase + ch.start) * 2 * BB;
         for (int i = tid; i < (len + 1) * BB; i += NT) {
             const int pos = i / BB, r = i - pos * BB;

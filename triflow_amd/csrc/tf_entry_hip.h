@@ -68,12 +68,7 @@ __device__ __forceinline__ void tfk_l1_factor_any(const TfLevelArgs& a) {
 extern "C" {
 
 // ---- stencil sweeps: block (64,1,1), grid (chunks/64, segments) ------------
-// TF_SWEEP_WAVES (optional): occupancy the register allocator has to make room for
-#ifdef TF_SWEEP_WAVES
-#define TF_SWEEP_ATTR __attribute__((amdgpu_waves_per_eu(TF_SWEEP_WAVES)))
-#else
 #define TF_SWEEP_ATTR
-#endif
 __global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_sweep_f(TfSweepArgs a) {
     tfk_sweep_body<false>(a, TF_GID, blockIdx.y);
 }
@@ -151,7 +146,7 @@ __global__ void __launch_bounds__(256) tfk_vec_maxabs(TfVecArgs a) {
 }
 
 __global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_berr(TfBerrArgs a) {
-    const double m = tfk_berr_body(a, (int)((blockIdx.x * a.blk_stride + a.blk_phase) * blockDim.x + threadIdx.x), blockIdx.y);
+    const double m = tfk_berr_body(a, TF_GID, blockIdx.y);
     unsigned long long bits = (unsigned long long)__double_as_longlong(m);
     if (m != m) bits = 0x7ff8000000000000ull;
 #pragma unroll
@@ -377,6 +372,11 @@ __global__ void __launch_bounds__(512) tfk_s_fwd(TfScalarArgs t) {
         const int tid = threadIdx.x;
         const TfCrChunk<TF_B2> ch(l2.L, (int)blockIdx.x);
         const int P1 = l1.L.P;
+        // the stored reductions of this level-2 chunk and of level 3's one chunk: requested before the
+        // walks (they do not depend on the right-hand side), so that neither level waits for memory
+        __shared__ double sF2[(TF_CRS_MAXLEN + 1) * 5 * TF_B2 * TF_B2], sF3[(TF_CRS_MAXLEN + 1) * 5 * TF_B2 * TF_B2];
+        tfk_crs_stage<TF_B2, 512>(l2, (int)blockIdx.x, tid, sF2);
+        tfk_crs_stage<TF_B2, 512>(t.lv[2], ch.e, tid, sF3);
         if (tid < 256) {
             if (tid < ch.len) tfk_chunk_body<TfRowsL1, +1, false, false, true>(l1, ch.e * P1 + ch.start + tid);
         } else if (tid - 256 < ch.len) {
@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(512) tfk_s_fwd(TfScalarArgs t) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        tfk_crs_fwd<TF_B2, 512>(l2, (int)blockIdx.x, tid);
+        tfk_crs_fwd<TF_B2, 512, true>(l2, (int)blockIdx.x, tid, sF2);
         // ---- the workgroup of this system that arrives last solves level 3
         __shared__ int last;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(512) tfk_s_fwd(TfScalarArgs t) {
             last = is_last;
         }
         __syncthreads();
-        if (last) tfk_crs_fwd<TF_B2, 512>(t.lv[2], ch.e, tid);
+        if (last) tfk_crs_fwd<TF_B2, 512, true>(t.lv[2], ch.e, tid, sF3);
     }
 }
 __global__ void __launch_bounds__(512) tfk_s_bwd(TfScalarArgs t) {

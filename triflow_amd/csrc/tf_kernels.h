@@ -389,6 +389,10 @@ TF_DEVICE double tfk_berr_body(const TfBerrArgs& a, int pg, int seg) {
     if (pg >= L.Ptot) return 0.0;
     const int e = pg / L.P, p = pg - e * L.P;
     const int len = tf_len(L, p);
+    // (sampled form: the one node of this chunk that is looked at, as segment + place in it)
+    const int pick = a.one_node >= 0 ? a.one_node % len : -1;
+    if (pick >= 0) seg = pick / TF_SEG;
+    const int jlo = pick >= 0 ? pick - seg * TF_SEG : 0, jhi = pick >= 0 ? jlo + 1 : TF_SEG;
     const int i0 = seg * TF_SEG;
     if (i0 >= len) return 0.0;
     const bool based = a.xbase != nullptr;
@@ -404,14 +408,14 @@ TF_DEVICE double tfk_berr_body(const TfBerrArgs& a, int pg, int seg) {
 #pragma unroll
     for (int v = 0; v < TF_NVAR; ++v)
 #pragma unroll
-        for (int o = 1; o < TF_W; ++o) ld(v, i0 - TF_MP + o - 1, w[v][o], wm[v][o]);
+        for (int o = 1; o < TF_W; ++o) ld(v, i0 + jlo - TF_MP + o - 1, w[v][o], wm[v][o]);
     TfJUniform ju;
     ju.init(a.parsca, a.dx, L.nsys, e);
     double worst = 0.0;
 #pragma unroll
     for (int j = 0; j < TF_SEG; ++j) {
         const int i = i0 + j;
-        if (i < len) {
+        if (i < len && j >= jlo && j < jhi) {
 #pragma unroll
             for (int v = 0; v < TF_NVAR; ++v) {
 #pragma unroll

@@ -47,9 +47,6 @@ TfLayout make_layout(int nsys, int N, int P, int periodic) {
     L.Ptot = nsys * P;
     L.periodic = periodic;
     L.plane = (int64_t)L.M * L.Ptot;
-    // planes are spaced by `plane` elements; TRIFLOW_PLANE_PAD (elements) offsets consecutive
-    // planes against each other (experiments on HBM channel aliasing of the many-plane walks)
-    if (const char* v = getenv("TRIFLOW_PLANE_PAD")) L.plane += atoll(v);
     return L;
 }
 
@@ -152,11 +149,16 @@ struct tf_solver {
     unsigned cr_block() const { return top.B <= 2 ? 256u : 64u; }     // TF_CR_BLOCK of tf_entry_hip.h
     // wavefront for each of the 8 nodes of round 1; a level with more chunks than the GPU
     // holds at once (4 such workgroups per CU) takes 4 wavefronts per chunk, twice the chunks in flight
+    // (3 <= b <= 7, tf_cr3_hip.h: 2 wavefronts and 20 KB of LDS per chunk -- eight chunks per CU, 2048 on
+    // the GPU: every chunk of a level of up to that many is resident at once; b = 8, tf_cr2_hip.h: 4 or 8)
     unsigned cr_factor_block(int64_t chunks) const {
         if (top.B <= 2) return 256u;
-        const char* v = getenv("TRIFLOW_CR_FACTOR_BLOCK");
-        if (v) return atoi(v) >= 512 ? 512u : 256u;      // (the kernel is written for 4 or 8 wavefronts)
-        return chunks > 1024 ? 256u : 512u;
+        const unsigned least = top.B <= 7 ? 128u : 256u;
+        if (const char* v = getenv("TRIFLOW_CR_FACTOR_BLOCK")) {
+            const int want = atoi(v);
+            return want >= 512 ? 512u : (want >= 256 ? 256u : least);
+        }
+        return chunks > 1024 ? least : 512u;
     }
     // the last level is a cyclic-reduction level: it handles the top block itself
     bool fold_top() const { return levels.size() > 1 && levels.back()->cr; }
@@ -380,8 +382,7 @@ struct tf_solver {
     // crossing to the memory side (the extra workgroups find pg >= Ptot and leave).
     unsigned sweep_gx() const {
         const unsigned gx = cdiv(L1.Ptot, spec.sweep_block);
-        static const bool xcd = getenv("TRIFLOW_XCD_GRID") ? atoi(getenv("TRIFLOW_XCD_GRID")) != 0 : true;
-        return (xcd && gx > 8) ? (gx + 7u) / 8u * 8u : gx;
+        return gx > 8 ? (gx + 7u) / 8u * 8u : gx;      // (a multiple of the 8 XCDs: DESIGN.md, sweep grid)
     }
 
     // ------------------------------------------------------ elementary steps
@@ -453,8 +454,7 @@ struct tf_solver {
         if (with_j) { have_jac = true; have_factor = false; }
     }
     // (the fused sweeps of the theta and BDF-2 steps do not store F next to the right-hand side it is
-    // part of; TRIFLOW_FUSED_STORE_F=1: A/B runs)
-    bool store_f_fused = false;
+    // part of: tf_get_F after a step is unspecified, include/triflow_hip.h)
     // F, J, the BDF-2 right-hand side and the history update Uprev <- U in one pass
     void sweep_bdf2(const double* fields, bool two_step, double c0, double c1, double* rhs,
                     const double* prev, double* prev_out) {
@@ -462,7 +462,7 @@ struct tf_solver {
         std::memset(&a, 0, sizeof(a));
         a.fscale = 1.0;
         a.L = L1; a.fields = fields; a.helpers = helpers.p; a.parvec = parvec.p; a.parsca = parsca.p;
-        a.dx = dx.p; a.xcoord = xcoord.p; a.F = store_f_fused ? F.p : nullptr; a.Jv = Jv.p; a.with_j = 1;
+        a.dx = dx.p; a.xcoord = xcoord.p; a.F = nullptr; a.Jv = Jv.p; a.with_j = 1;
         a.bdf_rhs = rhs; a.bdf_prev = prev; a.bdf_prev_out = prev_out; a.bdf_c0 = c0; a.bdf_c1 = c1; a.bdf_two_step = two_step ? 1 : 0;
         unsigned gx = sweep_gx(), gy = cdiv(L1.M, spec.seg);
         launch(TFK_SWEEP_FJ_BDF2, gx, gy, spec.sweep_block, &a, sizeof(a));
@@ -474,7 +474,7 @@ struct tf_solver {
         std::memset(&a, 0, sizeof(a));
         a.fscale = 1.0;
         a.L = L1; a.fields = fields; a.helpers = helpers.p; a.parvec = parvec.p; a.parsca = parsca.p;
-        a.dx = dx.p; a.xcoord = xcoord.p; a.F = store_f_fused ? F.p : nullptr; a.Jv = Jv.p; a.with_j = 1;
+        a.dx = dx.p; a.xcoord = xcoord.p; a.F = nullptr; a.Jv = Jv.p; a.with_j = 1;
         a.theta_rhs = rhs; a.theta = theta; a.theta_dt = dt;
         unsigned gx = sweep_gx(), gy = cdiv(L1.M, spec.seg);
         launch(TFK_SWEEP_FJ_THETA, gx, gy, spec.sweep_block, &a, sizeof(a));
@@ -526,7 +526,7 @@ struct tf_solver {
     bool wants_alt(double c) const {
         return jconst && two_slots && !reuse_ok(c) && !alt_ok(c) && cf_valid && have_jac && cf_ver == par_ver;
     }
-    bool two_slots = true;         // (TRIFLOW_TWO_FACTORS=0: A/B runs)
+    bool two_slots = true;
     void ensure_alt() {
         if (alt_allocated) return;
         for (size_t l = 0; l < levels.size(); ++l) {
@@ -667,8 +667,7 @@ struct tf_solver {
         const size_t lds = (size_t)2 * a.ylds_rows * spec.nvar * 64 * sizeof(double);
         // (up to half of a CU's 160 KB: two workgroups = four wavefronts, one per SIMD; the stiff model's
         // 80 KB just fit -- config 5 687 -> 698 steps/s, profiles/r03_ab_runs.txt r3n)
-        static const size_t lds_max = getenv("TRIFLOW_L1_LDS_MAX") ? (size_t)atoll(getenv("TRIFLOW_L1_LDS_MAX")) : 80u * 1024u;
-        return lds <= lds_max ? (unsigned)lds : 0u;
+        return lds <= 80u * 1024u ? (unsigned)lds : 0u;
     }
     TfLevelArgs level_args(size_t l, const double* rhs1, double* x1) {
         Level& lv = *levels[l];
@@ -842,7 +841,7 @@ struct tf_solver {
     }
     // The two last levels of a solve go in one launch (tfk_cr_tail) when both are cyclic-reduction
     // levels of 3 <= b <= 6 and the first of them has at most 8 chunks per system
-    bool cr_tail = true;           // (TRIFLOW_CR_TAIL=0: A/B runs)
+    bool cr_tail = true;
     bool tail_ok() const {
         const size_t n = levels.size();
         return cr_tail && tfb::is_device_build() && n >= 3 && top.B >= 3 && top.B <= 6 && levels[n - 1]->cr && levels[n - 2]->cr &&
@@ -897,7 +896,7 @@ struct tf_solver {
         TfBerrArgs a;
         std::memset(&a, 0, sizeof(a));
         a.L = L1; a.Jv = Jv.p; a.x = x1; a.rhs = rhs1; a.c = factor_c; a.red = red.p;
-        a.parsca = parsca.p; a.dx = dx.p; a.blk_stride = 1;
+        a.parsca = parsca.p; a.dx = dx.p; a.one_node = -1;
         unsigned gx = sweep_gx(), gy = cdiv(L1.M, spec.seg);
         launch(TFK_BERR, gx, gy, spec.sweep_block, &a, sizeof(a));
         double h = 0;
@@ -906,13 +905,13 @@ struct tf_solver {
     }
     // The monitor of the Theta and BDF-2 steps (the Rosenbrock steps have theirs inside the J @ v pass
     // of stage 1, tfk_spmv_mon): between two synchronising checks every new factorisation has the same
-    // backward error measured on one workgroup in TF_MON_STRIDE of the full pass (a rotating sixteenth of
-    // the chunks: ~1 % of a step of config 5), with no host wait -- the maximum goes to red[4] and is
-    // looked at by the next synchronising call, like the Rosenbrock monitor's.  A factorisation that
-    // lost accuracy did so because of what the matrix is like, i.e. in many chunks at once.
+    // backward error measured at ONE node of every level-1 chunk -- a different one in every step, so
+    // that every chunk's elimination is probed in every step and every row once per chunk length (32
+    // steps) -- with no host wait: a thread per chunk, ~45 loads each (config 5: 45 MB, ~1 % of a step;
+    // the full pass is 576 MB).  The maximum goes to red[4] and is looked at by the next synchronising
+    // call, like the Rosenbrock monitor's.
     // xbase: the state the step started from, when x1 is the new state of a step whose solve leaves
     // U + delta instead of delta (TfBerrArgs::xbase).
-    static constexpr unsigned TF_MON_STRIDE = 16;
     unsigned mon_phase = 0;
     bool sampled_monitor_due() const {
         return refine < 0 && !reused && !delegated && !tiny && have_factor && !(refine == -1 && check_now);
@@ -922,11 +921,9 @@ struct tf_solver {
         std::memset(&a, 0, sizeof(a));
         a.L = L1; a.Jv = Jv.p; a.x = x1; a.rhs = rhs1; a.c = factor_c; a.red = red.p + 4;
         a.parsca = parsca.p; a.dx = dx.p; a.xbase = xbase;
-        const unsigned gx = sweep_gx(), gy = cdiv(L1.M, spec.seg);
-        const unsigned stride = gx >= 4 * TF_MON_STRIDE ? TF_MON_STRIDE : 1;     // (small grids: the whole pass is a few us)
-        a.blk_stride = (int)stride; a.blk_phase = (int)(mon_phase++ % stride);
-        const unsigned n = (gx - (unsigned)a.blk_phase + stride - 1) / stride;
-        launch(TFK_BERR, n, gy, spec.sweep_block, &a, sizeof(a));
+        // (a stride coprime with every chunk length up to 64: consecutive steps look at nodes far apart)
+        a.one_node = (int)((mon_phase++ * 13u) % 4096u);
+        launch(TFK_BERR, sweep_gx(), 1, spec.sweep_block, &a, sizeof(a));
         monitored = true;
     }
     // x = (I - c J)^-1 rhs.  refine > 0: that many refinement sweeps; refine == -1
@@ -1160,14 +1157,11 @@ tf_solver* make_solver(tf_model* model, int64_t N, int32_t nsys, int32_t periodi
     s->graphs_on = tfb::graphs_supported() && (int64_t)N * nsys <= 50000;
     if (const char* v = getenv("TRIFLOW_GRAPHS")) s->graphs_on = tfb::graphs_supported() && atoi(v) != 0;
     if (const char* v = getenv("TRIFLOW_FUSE_STAGE")) s->fuse_stage = atoi(v) != 0;      // A/B runs
-    if (const char* v = getenv("TRIFLOW_CR_TAIL")) s->cr_tail = atoi(v) != 0;
     if (const char* v = getenv("TRIFLOW_S_FUSE")) s->s_fuse = atoi(v) != 0;
     if (const char* v = getenv("TRIFLOW_L1_FUSE_BACKSUB")) s->l1_fuse_backsub = atoi(v) != 0;
-    if (const char* v = getenv("TRIFLOW_TWO_FACTORS")) s->two_slots = atoi(v) != 0;
     if (const char* v = getenv("TRIFLOW_L1_FUSE_ASM")) s->l1_fuse_asm = atoi(v) != 0;
     if (const char* v = getenv("TRIFLOW_FUSE_UPDATE")) s->upd_fuse = atoi(v) != 0;
     if (const char* v = getenv("TRIFLOW_HOOK_IN_PLACE")) s->hook_in_place = atoi(v) != 0;
-    if (const char* v = getenv("TRIFLOW_FUSED_STORE_F")) s->store_f_fused = atoi(v) != 0;
     s->l1_respike = TF_RESPIKE_MODEL(sp.mp, sp.nvar) && (int64_t)N * nsys >= TF_RESPIKE_MIN_NODES;
     if (const char* v = getenv("TRIFLOW_L1_TWIST")) s->l1_twist = atoi(v) != 0 ? 1 : 0;
     if (const char* v = getenv("TRIFLOW_L1_RESPIKE"))                                   // A/B runs, tests
