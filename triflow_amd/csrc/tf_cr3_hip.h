@@ -27,7 +27,8 @@
 //     offsets worked out once per kernel; z leaves through LDS as one contiguous store per chunk.
 // Stored quantities (a.crf, a.zt, a.Anext, a.rhsnext, a.perm) and their formats are those of
 // tfk_cr_factor_v3: tfk_cr_fwd / tfk_cr_bwd / tfk_cr_tail read them unchanged.  b = 8 (33 augmented
-// columns: more than a half wavefront) keeps the round-3 kernel.  HIP only.
+// columns: more than a half wavefront) runs with one copy of the columns over the 64 lanes and the two
+// neighbours one after the other.  HIP only.
 #pragma once
 
 template <int BB> struct TfCr3 {
@@ -38,7 +39,10 @@ template <int BB> struct TfCr3 {
     static constexpr int RS = (4 * BB + 3) | 1;          // odd: rows of a position start on different banks
     static constexpr int PS = BB * RS;
     static constexpr int NC = 4 * BB + 1;                // augmented columns [L | D | U | y | I]
-    static_assert(NC <= 32, "a half wavefront holds the augmented columns");
+    // b <= 7: the columns fit a half wavefront and both halves hold them (one half per neighbour);
+    // b = 8 ... 15: one copy over the 64 lanes, the two neighbours one after the other
+    static constexpr bool DUP = NC <= 32;
+    static_assert(NC <= 64, "a wavefront holds the augmented columns");
 };
 
 // store to a wave-uniform base + 32-bit lane byte offset (saddr form: no 64-bit lane arithmetic)
@@ -74,26 +78,23 @@ __device__ __forceinline__ void tf_gj3_step(double (&val)[BB], int c, bool& grow
 template <int BB>
 __device__ __forceinline__ void tfk_cr_factor_v4(const TfLevelArgs& a) {
     typedef TfCr3<BB> C;
-    constexpr int NPOS = C::NPOS, B2 = BB * BB, REC = 4 * B2, NT_MIN = 128;
+    constexpr int NPOS = C::NPOS, B2 = BB * BB, REC = 4 * B2, NT_MIN = 256;
     constexpr int RS = C::RS, PS = C::PS, NC = C::NC;
     constexpr int oL = C::oL, oDL = C::oDL, oU = C::oU, oYL = C::oYL, oDR = C::oDR, oYR = C::oYR, oZ = C::oZ;
     constexpr int NO = 2 * BB + 1;                       // outputs of one side of the share
     constexpr int NQ = (2 * B2 + 63) / 64;               // instructions that copy the U_a, L_b blocks (2 b^2 entries)
-    const int NT = blockDim.x, nw = NT >> 6;             // 8 wavefronts per chunk, or 2 (levels with many chunks)
+    const int NT = blockDim.x, nw = NT >> 6;             // 8 wavefronts per chunk, or 4 (levels with many chunks)
     const TfLayout& L = a.L;
     const TfCrChunk<BB> ch(L, (int)blockIdx.x);
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int half = lane >> 5, c = lane & 31;
+    constexpr bool DUP = C::DUP;
+    const int half = DUP ? lane >> 5 : 0, c = DUP ? lane & 31 : lane;
     const int mI = ch.mI, pe = ch.pe, len = ch.len;
     const bool with_rhs = a.cr_rhs != 0;
 
-    // Position pe (the chunk's own separator) only ever uses the L side of its row -- L, DL, yL --
-    // and position 0 (the separator above) only the U side -- U, DR, yR: the two share one row.
-    // 16 rows of 26 doubles x b: 20 KB for b = 6, eight chunks per CU, so that the 1954 chunks of
-    // config 3's biggest reduced level are all resident at once (with 2 wavefronts each).
-    __shared__ double sRow[(NPOS - 1) * PS];
+    __shared__ double sRow[NPOS * PS];
     __shared__ unsigned sPerm[NPOS + 1];                 // stored pivot order of the chunk's nodes
-    auto row = [&](int pos, int r) { return sRow + (pos == pe ? 0 : pos) * PS + r * RS; };
+    auto row = [&](int pos, int r) { return sRow + pos * PS + r * RS; };
     unsigned* const perm = a.perm + ch.nbase + ch.start; // [node]; the top block's follows the nodes
     if (tid < len) sPerm[tid + 1] = perm[tid];
     unsigned* const perm_top = a.perm + (int64_t)L.nsys * L.N + ch.e;    // (fold_top: P == 1, one per system)
@@ -111,12 +112,15 @@ __device__ __forceinline__ void tfk_cr_factor_v4(const TfLevelArgs& a) {
     // record [Dinv | E | F | Ua | Lb][b][b] of node k: this lane's column of blocks 0 - 2
     const bool grec = half == 0 && (cL || cU || cI);
     const unsigned goff = (unsigned)((cI ? idc : (cL ? B2 + c : 2 * B2 + c - 2 * BB)) * 8);
-    // neighbour update: half 0 works on a = k - s with U_a, half 1 on b = k + s with L_b
-    const int opoff = half ? oL : oU;
+    // neighbour update: side 0 works on a = k - s with U_a, side 1 on b = k + s with L_b (with both
+    // halves holding the columns: half = side; else the lanes take the sides one after the other)
     const bool pvalid = cL || cU || cY;
-    const bool pacc = half == 0 ? (cL || cY) : (cU || cY);
-    const int pslot = half == 0 ? (cL ? oDR + c : (cU ? oU + c - 2 * BB : oYR))
-                                : (cL ? oL + c : (cU ? oDL + c - 2 * BB : oYL));
+    auto pacc_of = [&](int sd) { return sd == 0 ? (cL || cY) : (cU || cY); };
+    auto pslot_of = [&](int sd) { return sd == 0 ? (cL ? oDR + c : (cU ? oU + c - 2 * BB : oYR))
+                                                 : (cL ? oL + c : (cU ? oDL + c - 2 * BB : oYL)); };
+    const int pslot0 = pslot_of(DUP ? half : 0), pslot1 = pslot_of(1);
+    const bool pacc0 = pacc_of(DUP ? half : 0), pacc1 = pacc_of(1);
+    const int opoff0 = (DUP ? half : 0) ? oL : oU;
     // copies of the blocks used in the elimination (record blocks 3, 4 = U_a, L_b before the update)
     int crel[NQ];
     bool cside[NQ], cok[NQ];
@@ -150,26 +154,29 @@ __device__ __forceinline__ void tfk_cr_factor_v4(const TfLevelArgs& a) {
         if (tid < B2 && ch.has_prev) p0 = prev[tid];
         const double* ys = a.rhs + (ch.nbase + ch.start) * 2 * BB;
         if (with_rhs && tid < len * BB) y0 = ys[(tid / BB) * 2 * BB + tid % BB] + ys[(tid / BB) * 2 * BB + BB + tid % BB];
-        // everything that is not loaded: every DR, yR, yL and the zero slot (rows 0 .. len - 1: the
-        // separator's row is row 0)
-        for (int i = tid; i < len * BB * (RS - 3 * BB); i += NT) {
+        // everything that is not loaded: position 0's L and DL, every DR, yR, yL and the zero slot
+        for (int i = tid; i < (len + 1) * BB * (RS - 3 * BB); i += NT) {
             const int pr = i / (RS - 3 * BB), o = i - pr * (RS - 3 * BB);
             sRow[(pr / BB) * PS + (pr % BB) * RS + 3 * BB + o] = 0.0;
+        }
+        if (tid < 3 * B2) {
+            const int blk = tid / B2, rc = tid - blk * B2, r = rc / BB, cc = rc - r * BB;
+            row(0, r)[blk * BB + cc] = 0.0;
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = it * NT + tid;
             const int nd = i / (3 * B2), rem = i - nd * 3 * B2, blk = rem / B2, rc = rem - blk * B2;
             const int r = rc / BB, cc = rc - r * BB;
-            // (the separator's U block couples to the next chunk: not used here, and its place is position 0's)
-            if (i < n3 && !(nd + 1 == pe && blk == 2)) row(nd + 1, r)[blk * BB + cc] = v[it] + v2[it];
+            if (i < n3) row(nd + 1, r)[blk * BB + cc] = v[it] + v2[it];
         }
         __syncthreads();
         if (tid < B2) row(0, tid / BB)[oU + tid % BB] = p0;
         if (tid < len * BB) row(tid / BB + 1, tid % BB)[oYL] = y0;
-        // no neighbour above the first node of a system (len == 1: that node is the separator, whose
-        // L block then shares the row of position 0 -- which holds no coupling either: p0 is zero)
-        if (!L.periodic && ch.start == 0 && tid < B2) row(1, tid / BB)[oL + tid % BB] = 0.0;
+        if (!L.periodic) {                           // no neighbour beyond the ends of a system
+            if (ch.start == 0 && tid < B2) row(1, tid / BB)[oL + tid % BB] = 0.0;
+            if (ch.start + len == L.N && tid >= 64 && tid < 64 + B2) row(pe, (tid - 64) / BB)[oU + (tid - 64) % BB] = 0.0;
+        }
     }
     __syncthreads();
 
@@ -185,12 +192,16 @@ __device__ __forceinline__ void tfk_cr_factor_v4(const TfLevelArgs& a) {
             const double* rk = row(k, 0);
             double* ra = row(ia, 0);
             double* rb = row(ib, 0);
-            double* nb = half ? rb : ra;             // the neighbour this half updates
+            double* nb = (DUP && half) ? rb : ra;    // the neighbour this half updates (one copy: the first of the two)
             if (r == 1) TF_STAMP(a, 44);
             // requested first, used last: what the neighbour rows hold now
-            double old[BB], cp[NQ];
+            double old[BB], old1[DUP ? 1 : BB], cp[NQ];
 #pragma unroll
-            for (int i = 0; i < BB; ++i) old[i] = nb[i * RS + pslot];
+            for (int i = 0; i < BB; ++i) old[i] = nb[i * RS + pslot0];
+            if constexpr (!DUP) {
+#pragma unroll
+                for (int i = 0; i < BB; ++i) old1[i] = rb[i * RS + pslot1];
+            }
 #pragma unroll
             for (int q = 0; q < NQ; ++q) cp[q] = (cside[q] ? rb : ra)[crel[q]];
             // ---- the block inversion of node k, rows in the remembered order
@@ -265,8 +276,8 @@ __device__ __forceinline__ void tfk_cr_factor_v4(const TfLevelArgs& a) {
             }
             if (r == 1) TF_STAMP(a, 46);
             // ---- the neighbours: out = -(U_a | L_b) * (my column of E, F, z)
-            {
-                const double* opb = nb + opoff;
+            auto update = [&](double* nbp, int opoff, int pslot, bool pacc, const double* oldv) {
+                const double* opb = nbp + opoff;
                 double out[BB];
 #pragma unroll
                 for (int i = 0; i < BB; ++i) {
@@ -275,12 +286,14 @@ __device__ __forceinline__ void tfk_cr_factor_v4(const TfLevelArgs& a) {
                     for (int m = 0; m < BB; ++m) acc = tf_fma(-opb[i * RS + m], val[m], acc);
                     out[i] = acc;
                 }
-                if (r == 1) TF_STAMP(a, 47);
                 if (pvalid) {
 #pragma unroll
-                    for (int i = 0; i < BB; ++i) nb[i * RS + pslot] = (pacc ? old[i] : 0.0) + out[i];
+                    for (int i = 0; i < BB; ++i) nbp[i * RS + pslot] = (pacc ? oldv[i] : 0.0) + out[i];
                 }
-            }
+            };
+            update(nb, opoff0, pslot0, pacc0, old);
+            if (r == 1) TF_STAMP(a, 47);
+            if constexpr (!DUP) update(rb, oL, pslot1, pacc1, old1);
             if (r == 1) TF_STAMP(a, 48);
         }
         TF_STAMP(a, stamp_i); ++stamp_i;
@@ -300,10 +313,10 @@ __device__ __forceinline__ void tfk_cr_factor_v4(const TfLevelArgs& a) {
         const int nn = side == 0 ? ch.p : ch.pprev;
         double* rec = a.Anext + ((int64_t)ch.e * a.Lnext.N + nn) * REC;
         double* rr = a.rhsnext + ((int64_t)ch.e * a.Lnext.N + nn) * 2 * BB;
-        const double* rs = row(0, r);                 // (positions pe and 0 share it: L side / U side)
+        const double* rs = row(side == 0 ? pe : 0, r);
         if (o < BB) rec[(side == 0 ? 0 : 2) * B2 + r * BB + o] = rs[(side == 0 ? oL : oU) + o];
-        else if (o < 2 * BB) rec[(side == 0 ? 1 : 3) * B2 + r * BB + o - BB] = rs[(side == 0 ? oDL : oDR) + o - BB];
-        else if (with_rhs) rr[(side == 0 ? 0 : BB) + r] = rs[side == 0 ? oYL : oYR];
+        else if (o < 2 * BB) rec[(side == 0 ? 1 : 3) * B2 + r * BB + o - BB] = rs[oDL + o - BB] + rs[oDR + o - BB];
+        else if (with_rhs) rr[(side == 0 ? 0 : BB) + r] = rs[oYL] + rs[oYR];
     }
     TF_STAMP(a, 20);
     if (a.fold_top) {
@@ -313,14 +326,16 @@ __device__ __forceinline__ void tfk_cr_factor_v4(const TfLevelArgs& a) {
         constexpr int NCT = 2 * BB + 1, NJT = (NCT + 7) / 8;     // [S | y | I]
         const int g = lane & 7, h = lane >> 3;
         if (w == 0) {
-            const double* r0 = row(0, 0);             // (L, DL, yL: the separator's; U, DR, yR: position 0's)
+            const double* r0 = row(0, 0);
+            const double* rp = row(pe, 0);
             double val[NJT];
             unsigned code = sPerm[0];
             const unsigned code0 = code;
             const int myk = tf_gj_node<BB, NCT, 0>(val, g, h, code, ok, [&](int rr, int cc) {
                 const int o = rr * RS;
-                return rr < 0 ? 0.0 : (cc < BB ? r0[o + oL + cc] + r0[o + oDL + cc] + r0[o + oU + cc] + r0[o + oDR + cc]
-                       : (cc == BB ? r0[o + oYL] + r0[o + oYR]
+                return rr < 0 ? 0.0 : (cc < BB ? rp[o + oL + cc] + (rp[o + oDL + cc] + rp[o + oDR + cc]) + r0[o + oU + cc]
+                                                     + (r0[o + oDL + cc] + r0[o + oDR + cc])
+                       : (cc == BB ? (rp[o + oYL] + rp[o + oYR]) + (r0[o + oYL] + r0[o + oYR])
                                    : ((cc < NCT && cc - BB - 1 == rr) ? 1.0 : 0.0))); });
             if (code != code0 && lane == 0) *perm_top = code;
             if (g < BB) {
@@ -334,8 +349,8 @@ __device__ __forceinline__ void tfk_cr_factor_v4(const TfLevelArgs& a) {
                         const double x = val[j];
                         a.topx[(int64_t)ch.e * BB + myk] = x;
                         a.x[(ch.nbase + ch.node(pe)) * BB + myk] = x;
-                        row(0, myk)[oYL] = x;                          // position pe
-                        row(0, myk)[oYR] = ch.has_prev ? x : 0.0;      // position 0
+                        row(pe, myk)[oYL] = x;
+                        row(0, myk)[oYL] = ch.has_prev ? x : 0.0;
                     }
                 }
             }
@@ -356,7 +371,7 @@ __device__ __forceinline__ void tfk_cr_factor_v4(const TfLevelArgs& a) {
                     double xk = rk[oYL];
 #pragma unroll
                     for (int m = 0; m < BB; ++m) {
-                        xk = tf_fma(-rk[oL + m], row(kl, m)[kl == 0 ? oYR : oYL], xk);
+                        xk = tf_fma(-rk[oL + m], row(kl, m)[oYL], xk);
                         xk = tf_fma(-rk[oU + m], row(kr, m)[oYL], xk);
                     }
                     rk[oYL] = xk;

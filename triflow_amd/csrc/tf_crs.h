@@ -12,7 +12,14 @@
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 #define TF_LDS __shared__
 #define TF_BARRIER() __syncthreads()
+// 8-byte agent-scope accesses (global_store / global_load ... sc1: written through to memory, read
+// past the L1): the hand-off of a level's right-hand side share to another workgroup of the same
+// launch (tfk_s_fwd) without writing back / invalidating whole caches
+#define TF_ST_AGENT(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define TF_LD_AGENT(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #else
+#define TF_ST_AGENT(p, v) (*(p) = (v))
+#define TF_LD_AGENT(p) (*(p))
 #define TF_LDS static thread_local
 #define TF_BARRIER() do {} while (0)
 #endif
@@ -238,7 +245,9 @@ TF_DEVICE void tfk_crs_stage(const TfLevelArgs& a, int chunk, int tid, double* s
 
 // STAGED: the caller has put the stored reduction into `sF` already (tfk_crs_stage: a kernel that
 // walks level 1 first requests it before the walks, tfk_s_fwd)
-template <int BB, int NT, bool STAGED = false>
+// AGENT_OUT / AGENT_IN: this chunk's share of the next level's right-hand side is stored / this level's
+// right-hand side is loaded with agent-scope accesses (a producer / the consumer inside one launch)
+template <int BB, int NT, bool STAGED = false, bool AGENT_OUT = false, bool AGENT_IN = false>
 TF_DEVICE void tfk_crs_fwd(const TfLevelArgs& a, int chunk, int tid, double* sF_staged = nullptr) {
     typedef TfCrs<BB> C;
     constexpr int NPOS = C::NPOS, B2 = BB * BB;
@@ -253,7 +262,8 @@ TF_DEVICE void tfk_crs_fwd(const TfLevelArgs& a, int chunk, int tid, double* sF_
         const double* ys = a.rhs + (ch.nbase + ch.start) * 2 * BB;
         for (int i = tid; i < (len + 1) * BB; i += NT) {
             const int pos = i / BB, r = i - pos * BB;
-            sY[i] = pos > 0 ? ys[(pos - 1) * 2 * BB + r] + ys[(pos - 1) * 2 * BB + BB + r] : 0.0;
+            if (AGENT_IN) sY[i] = pos > 0 ? TF_LD_AGENT(ys + (pos - 1) * 2 * BB + r) + TF_LD_AGENT(ys + (pos - 1) * 2 * BB + BB + r) : 0.0;
+            else sY[i] = pos > 0 ? ys[(pos - 1) * 2 * BB + r] + ys[(pos - 1) * 2 * BB + BB + r] : 0.0;
         }
     }
     TF_BARRIER();
@@ -340,7 +350,11 @@ TF_DEVICE void tfk_crs_fwd(const TfLevelArgs& a, int chunk, int tid, double* sF_
         for (int side = tid; side < 2; side += NT) {
             const int nn = side == 0 ? ch.p : ch.pprev;
             double* rr = a.rhsnext + ((int64_t)ch.e * a.Lnext.N + nn) * 2 * BB;
-            for (int r = 0; r < BB; ++r) { if (side == 0) rr[r] = sY[pe * BB + r]; else rr[BB + r] = sY[r]; }
+            for (int r = 0; r < BB; ++r) {
+                double* dst = side == 0 ? rr + r : rr + BB + r;
+                const double v = side == 0 ? sY[pe * BB + r] : sY[r];
+                if (AGENT_OUT) TF_ST_AGENT(dst, v); else *dst = v;
+            }
         }
     }
 }

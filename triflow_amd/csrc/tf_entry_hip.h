@@ -339,12 +339,12 @@ __global__ void __launch_bounds__(64) tfk_tiny_solve(TfTinyArgs a) { tfk_tiny_so
 #define TF_CR_V4 1                 // 0: the round-3 factorisation (tf_cr2_hip.h) for every block size (A/B runs)
 #endif
 #ifndef TF_CR_FACTOR_WAVES
-#define TF_CR_FACTOR_WAVES 4       // wavefronts per SIMD the register allocator makes room for
+#define TF_CR_FACTOR_WAVES (TF_B2 >= 8 ? 2 : 4)     // wavefronts per SIMD the register allocator makes room for
 #endif
 __global__ void __attribute__((amdgpu_waves_per_eu(TF_CR_FACTOR_WAVES))) __launch_bounds__(TF_CR_FACTOR_BLOCK)
 tfk_cr_factor(TfLevelArgs a) {
     if constexpr (TF_B2 <= 2) tfk_crs_factor<TF_B2, 256>(a, (int)blockIdx.x, (int)threadIdx.x);
-    else if constexpr (TF_B2 <= 7 && TF_CR_V4) tfk_cr_factor_v4<TF_B2>(a);
+    else if constexpr (TF_B2 <= 8 && TF_CR_V4) tfk_cr_factor_v4<TF_B2>(a);
     else if constexpr (TF_B2 <= 8) tfk_cr_factor_v3<TF_B2>(a);
 }
 __global__ void __launch_bounds__(TF_CR_BLOCK) tfk_cr_fwd(TfLevelArgs a) {
@@ -388,25 +388,26 @@ __global__ void __launch_bounds__(512) tfk_s_fwd(TfScalarArgs t) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        tfk_crs_fwd<TF_B2, 512, true>(l2, (int)blockIdx.x, tid, sF2);
-        // ---- the workgroup of this system that arrives last solves level 3
+        tfk_crs_fwd<TF_B2, 512, true, true>(l2, (int)blockIdx.x, tid, sF2);
+        // ---- the workgroup of this system that arrives last solves level 3.  What changes hands between
+        // workgroups is this chunk's share of level 3's right-hand side, 2 b doubles: stored with
+        // agent-scope (write-through) stores by one wavefront, which waits for them and then counts
+        // itself in; the workgroup whose count came last reads the shares with agent-scope loads, the
+        // other wavefronts of it behind the barrier (MI355X_MICROARCH.md, hand-offs without the acquire:
+        // one lane per storing workgroup adds to one counter, the last adder learns it from the value
+        // returned) -- no write-back of the L2, no invalidate
         __shared__ int last;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (tid < 64) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned seen = __hip_atomic_fetch_add(t.counter + ch.e, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int is_last = seen == (unsigned)l2.L.P - 1u;
-            if (is_last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(t.counter + ch.e, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) {
+                const unsigned seen = __hip_atomic_fetch_add(t.counter + ch.e, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int is_last = seen == (unsigned)l2.L.P - 1u;
+                if (is_last) __hip_atomic_store(t.counter + ch.e, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = is_last;
             }
-            last = is_last;
         }
         __syncthreads();
-        if (last) tfk_crs_fwd<TF_B2, 512, true>(t.lv[2], ch.e, tid, sF3);
+        if (last) tfk_crs_fwd<TF_B2, 512, true, false, true>(t.lv[2], ch.e, tid, sF3);
     }
 }
 __global__ void __launch_bounds__(512) tfk_s_bwd(TfScalarArgs t) {

@@ -873,6 +873,13 @@ struct TfRowsBT {
 #ifndef TF_BACKSUB_DEPTH
 #define TF_BACKSUB_DEPTH 3
 #endif
+// ... as long as the ring fits the registers: `nd` doubles of factors per node; wide blocks keep
+// fewer nodes in flight instead of spilling (6 variables with 3-point stencils: 2, 5 with 5-point: 1)
+// (`other`: doubles the walk holds besides the ring -- the middle system of the twisted form)
+constexpr int tf_ring_depth(int nd, int other = 40) {
+    return TF_BACKSUB_DEPTH * nd + other <= 240 ? TF_BACKSUB_DEPTH
+         : (2 * nd + other <= 240 && TF_BACKSUB_DEPTH >= 2 ? 2 : 1);
+}
 
 // Twisted re-elimination (a.respike).  With the separators known, the interior of a chunk is a
 // banded system with known values on both sides, so it need not be swept end to end: the down
@@ -1808,7 +1815,7 @@ TF_DEVICE void tfk_backsub_body(const TfLevelArgs& a, int pg) {
     // TF_BACKSUB_DEPTH nodes of factors in flight per thread: the walk is a chain of loads
     // (few wavefronts: one lane per chunk), so its speed is the number of requests that are
     // outstanding, not the arithmetic.  The ring is unrolled: every index is static.
-    constexpr int D = TF_BACKSUB_DEPTH;
+    constexpr int D = tf_ring_depth(B + UW * B * B + (WITH_E ? MP * B * B : 0));
     Node ring[D];
 #pragma unroll
     for (int d = 0; d < D; ++d)
@@ -1970,7 +1977,7 @@ TF_DEVICE void tfk_backsub_twist_body(const TfLevelArgs& a, int pg, int dir,
     // the factors of the first streamed nodes are requested before the middle system is solved
     struct Node { double y[B]; double U[MP][B][B]; Upd u; };
     auto load = [&](int j, Node& n) { ldU(nat(j), n.U, n.y); upd_load(nat(j), n.u); };
-    constexpr int D = TF_BACKSUB_DEPTH;
+    constexpr int D = tf_ring_depth(3 * B + MP * B * B, 2 * (MP * B) * (MP * B) + 2 * MP * B + MP * B * B + B);
     Node ring[D];
 #pragma unroll
     for (int d = 0; d < D; ++d)

@@ -149,16 +149,11 @@ struct tf_solver {
     unsigned cr_block() const { return top.B <= 2 ? 256u : 64u; }     // TF_CR_BLOCK of tf_entry_hip.h
     // wavefront for each of the 8 nodes of round 1; a level with more chunks than the GPU
     // holds at once (4 such workgroups per CU) takes 4 wavefronts per chunk, twice the chunks in flight
-    // (3 <= b <= 7, tf_cr3_hip.h: 2 wavefronts and 20 KB of LDS per chunk -- eight chunks per CU, 2048 on
-    // the GPU: every chunk of a level of up to that many is resident at once; b = 8, tf_cr2_hip.h: 4 or 8)
     unsigned cr_factor_block(int64_t chunks) const {
         if (top.B <= 2) return 256u;
-        const unsigned least = top.B <= 7 ? 128u : 256u;
-        if (const char* v = getenv("TRIFLOW_CR_FACTOR_BLOCK")) {
-            const int want = atoi(v);
-            return want >= 512 ? 512u : (want >= 256 ? 256u : least);
-        }
-        return chunks > 1024 ? least : 512u;
+        const char* v = getenv("TRIFLOW_CR_FACTOR_BLOCK");
+        if (v) return atoi(v) >= 512 ? 512u : 256u;      // (the kernels are written for 4 or 8 wavefronts)
+        return chunks > 1024 ? 256u : 512u;
     }
     // the last level is a cyclic-reduction level: it handles the top block itself
     bool fold_top() const { return levels.size() > 1 && levels.back()->cr; }
@@ -1185,6 +1180,15 @@ tf_solver* make_solver(tf_model* model, int64_t N, int32_t nsys, int32_t periodi
         const bool dispersive_capable = sp.nvar == 1 && sp.mp >= 2;
         if (s->use_cr && !dispersive_capable)
             m1 = total <= 30000 ? 4 : (total <= 200000 ? 8 : (total <= 600000 ? 16 : 32));
+        // b <= 2 (round 4): a solve is two launches when the plan is [level 1 | 256-node chunks | one
+        // chunk] (tfk_s_fwd / tfk_s_bwd), i.e. while level 1 has at most 65 536 chunks per system; with
+        // the reduced levels that cheap the shortest such chunks win (config 2: m1 = 16 against 32:
+        // 19 400 against 18 400 steps/s, 16 000 against 14 600 factorising in every step,
+        // profiles/r04_ab_runs.txt)
+        if (s->use_cr && !dispersive_capable && b2 <= 2 && total > 600000) {
+            m1 = 16;
+            while (N / m1 > 65536) m1 *= 2;
+        }
     }
     m1 = std::max(m1, 2 * sp.mp);
     s->m1_used = m1; s->mup_used = mup;
