@@ -51,8 +51,10 @@ def test_product_has_no_cpu_fallback():
 def test_vec_op_enums_in_sync():
     with open(os.path.join(compilers.CSRC, "tf_kernels.h")) as f:
         k = dict(re.findall(r"(TF_VEC_[A-Z0-9_]+) = (\d+),", f.read()))
-    with open(os.path.join(compilers.CSRC, "tf_runtime.cpp")) as f:
-        r = dict(re.findall(r"(TF_VEC_[A-Z0-9_]+) = (\d+)", f.read()))
+    r = {}
+    for name in ("tf_solver.h",) + tuple(compilers.RUNTIME_SOURCES):
+        with open(os.path.join(compilers.CSRC, name)) as f:
+            r.update(re.findall(r"(TF_VEC_[A-Z0-9_]+) = (\d+)", f.read()))
     assert r and all(k[name] == val for name, val in r.items())
 
 

@@ -1,6 +1,6 @@
 """The model that made hipcc's spilling -O3 build give wrong solves (5 variables, 5-point
 stencils, b = 10: tools/gpu_wide_model_check2.py), run through the SAME kernel sources
-(csrc/tf_kernels.h, tf_runtime.cpp) compiled for the host at -O3 with AddressSanitizer and
+(csrc/tf_kernels.h, the host runtime) compiled for the host at -O3 with AddressSanitizer and
 UndefinedBehaviorSanitizer: an uninitialised array, an out-of-range constant index or a
 signed overflow in the shared source would show up here.  CPU only (the pool refuses GPU
 sanitizers).  Prints the solver error next to the sanitizer verdict."""

@@ -59,7 +59,7 @@ for name in ("kdv", "kuramoto"):
         fdk = dict(x=x, U=U)
         parsk = dict(periodic=True)
         order = 3 if name == "kdv" else 4
-        for ratio in (1e0, 1e2, 1e4, 1e6):
+        for ratio in (1e0, 1e2, 1e4, 1e6, 1e8, 1e10):
             dtk = ratio * dx ** order
             if dtk > 1.0:
                 continue

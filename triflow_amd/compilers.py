@@ -48,6 +48,9 @@ HIPCC_FLAGS = [*os.environ.get("TRIFLOW_HIPCC_OPT", "-O3").split(), "-std=c++17"
                "-ffp-contract=off", "--offload-arch=" + GPU_ARCH,
                *os.environ.get("TRIFLOW_HIPCC_EXTRA", "").split()]
 
+#: translation units of the host runtime (see the header of csrc/tf_solver.h)
+RUNTIME_SOURCES = ("tf_rt_plan.cpp", "tf_rt_io.cpp", "tf_rt_steps.cpp", "tf_rt_diag.cpp",
+                   "tf_solver_sweeps.cpp", "tf_solver_linear.cpp")
 _SKELETON = ("tf_args.h", "tf_math.h", "tf_kernels.h", "tf_crs.h", "tf_coop_hip.h", "tf_cr2_hip.h", "tf_cr3_hip.h", "tf_entry_hip.h")
 _TU_HEAD = ('#include <hip/hip_runtime.h>\n'
             '#define TF_DEVICE __device__ __forceinline__\n'
@@ -73,10 +76,10 @@ def _skeleton_stamp():
 
 
 def build_runtime_library(force=False):
-    """Compile ``csrc/tf_runtime.cpp`` + ``tf_backend_hip.cpp`` into
-    ``lib/libtriflow_hip.so`` (host code only; links libamdhip64)."""
-    srcs = [os.path.join(CSRC, "tf_runtime.cpp"), os.path.join(CSRC, "tf_backend_hip.cpp")]
-    deps = srcs + [os.path.join(CSRC, n) for n in ("tf_args.h", "tf_backend.h")] + \
+    """Compile the host runtime (``csrc/tf_rt_*.cpp``, ``tf_solver_*.cpp``: ``RUNTIME_SOURCES``) +
+    ``tf_backend_hip.cpp`` into ``lib/libtriflow_hip.so`` (host code only; links libamdhip64)."""
+    srcs = [os.path.join(CSRC, n) for n in RUNTIME_SOURCES] + [os.path.join(CSRC, "tf_backend_hip.cpp")]
+    deps = srcs + [os.path.join(CSRC, n) for n in ("tf_args.h", "tf_backend.h", "tf_solver.h")] + \
         [os.path.join(os.path.dirname(PKG_DIR), "include", "triflow_hip.h")]
     if not force and os.path.exists(LIB_PATH) and \
             all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):

@@ -1,4 +1,4 @@
-// Plain-data launch argument blocks shared by the host runtime (tf_runtime.cpp)
+// Plain-data launch argument blocks shared by the host runtime (tf_solver.h, tf_rt_*.cpp)
 // and the per-model kernels (tf_kernels.h).  Every kernel takes exactly one of
 // these structs by value.
 #pragma once

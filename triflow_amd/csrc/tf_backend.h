@@ -1,4 +1,4 @@
-// Device back end used by tf_runtime.cpp: memory, stream, code-object loading,
+// Device back end used by the host runtime (tf_solver.h): memory, stream, code-object loading,
 // kernel launch, event timing.  tf_backend_hip.cpp is the product
 // implementation (HIP on gfx950).  tests/emu/tf_backend_emu.cpp is a test-only
 // stand-in that executes the same kernel bodies thread by thread on the host so

@@ -1,6 +1,6 @@
 // __global__ entry points of a per-model code object (gfx950).  Included last
 // by the generated translation unit; names are fixed so that the host runtime
-// (tf_runtime.cpp, kernel table TF_KERNEL_NAMES) finds them with
+// (tf_solver.h, kernel table TF_KERNEL_NAMES) finds them with
 // hipModuleGetFunction.
 #pragma once
 
