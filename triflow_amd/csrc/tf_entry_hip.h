@@ -196,18 +196,12 @@ __global__ void __launch_bounds__(64) tfk_poke(TfPokeArgs a) {
 
 // ---- banded solver, level 1 (rows from the Jacobian planes) ----------------
 // grid.y: 0 = walk down, 1 = walk up (wave-uniform)
-// TF_L1_WAVES (A/B runs): ask the compiler for that many wavefronts per SIMD in the walks (the
-// window of a walk lives in registers: the film model's factorisation takes 356 of a lane's 512)
-#ifdef TF_L1_WAVES
-#define TF_L1_ATTR __attribute__((amdgpu_waves_per_eu(TF_L1_WAVES, TF_L1_WAVES)))
-#else
 #define TF_L1_ATTR
-#endif
 // the two wavefronts of a split factorisation walk share a SIMD: half the registers each
-#if !defined(TF_L1_WAVES) && TF_L1_SPLIT_ON
+#if TF_L1_SPLIT_ON
 #define TF_L1_FACTOR_ATTR __attribute__((amdgpu_waves_per_eu(2)))
 #else
-#define TF_L1_FACTOR_ATTR TF_L1_ATTR
+#define TF_L1_FACTOR_ATTR
 #endif
 __global__ void TF_L1_FACTOR_ATTR __launch_bounds__(TF_L1_FACTOR_BLOCK) tfk_l1_factor(TfLevelArgs a) { tfk_l1_factor_any<false>(a); }
 // factorisation that also eliminates a first right-hand side (the first solve of a
@@ -333,19 +327,15 @@ __global__ void __launch_bounds__(64) tfk_tiny_solve(TfTinyArgs a) { tfk_tiny_so
 // ---- cyclic-reduction levels (tf_coop_hip.h): 3 <= b <= 8 one wavefront per 16-node chunk
 //      (8 lanes per node); b <= 2 one thread per node, 256-node chunks
 #define TF_CR_BLOCK (TF_B2 <= 2 ? 256 : 64)
-// the factorisation of 3 <= b <= 8: up to 8 wavefronts per chunk (tf_cr2_hip.h)
+// the factorisation of 3 <= b <= 8: 4 or 8 wavefronts per chunk (tf_cr3_hip.h)
 #define TF_CR_FACTOR_BLOCK (TF_B2 <= 2 ? 256 : 512)
-#ifndef TF_CR_V4
-#define TF_CR_V4 1                 // 0: the round-3 factorisation (tf_cr2_hip.h) for every block size (A/B runs)
-#endif
 #ifndef TF_CR_FACTOR_WAVES
 #define TF_CR_FACTOR_WAVES (TF_B2 >= 8 ? 2 : 4)     // wavefronts per SIMD the register allocator makes room for
 #endif
 __global__ void __attribute__((amdgpu_waves_per_eu(TF_CR_FACTOR_WAVES))) __launch_bounds__(TF_CR_FACTOR_BLOCK)
 tfk_cr_factor(TfLevelArgs a) {
     if constexpr (TF_B2 <= 2) tfk_crs_factor<TF_B2, 256>(a, (int)blockIdx.x, (int)threadIdx.x);
-    else if constexpr (TF_B2 <= 8 && TF_CR_V4) tfk_cr_factor_v4<TF_B2>(a);
-    else if constexpr (TF_B2 <= 8) tfk_cr_factor_v3<TF_B2>(a);
+    else if constexpr (TF_B2 <= 8) tfk_cr_factor_v4<TF_B2>(a);
 }
 __global__ void __launch_bounds__(TF_CR_BLOCK) tfk_cr_fwd(TfLevelArgs a) {
     if constexpr (TF_B2 <= 2) tfk_crs_fwd<TF_B2, 256>(a, (int)blockIdx.x, (int)threadIdx.x);

@@ -135,17 +135,11 @@ TF_DEVICE int64_t tf_next_x(const TfLevelArgs& a, int e, int p, int64_t s2, int 
 // the backward-error monitor -- evaluate them once per thread from the scalar parameters,
 // with the very expressions of tf_eval_J (same bits), and only load the others.  Film model:
 // 10 of 19 entries are loaded, stiff model 11 of 24, scalar linear models none.
-#ifndef TF_USE_JUNIFORM
-#define TF_USE_JUNIFORM 1          // 0: read every entry back (A/B runs)
-#endif
-#define TF_JU(k) (TF_USE_JUNIFORM && tf_j_uniform[k])
+#define TF_JU(k) (tf_j_uniform[k])
 // ... and entries that are an exact power-of-two multiple of another node-dependent entry
 // (tf_j_alias / tf_j_alias_scale, codegen._proportional_entries: same bits as the stored value):
 // one load serves both.  Film model: 7 planes are loaded instead of 10.
-#ifndef TF_USE_JALIAS
-#define TF_USE_JALIAS 1            // 0: load every node-dependent entry (A/B runs)
-#endif
-#define TF_JA(k) (TF_USE_JALIAS && !TF_JU(k) && tf_j_alias[k] >= 0)
+#define TF_JA(k) (!TF_JU(k) && tf_j_alias[k] >= 0)
 struct TfJUniform {
     double v[TF_NNZ > 0 ? TF_NNZ : 1];
     TF_DEVICE_M void init(const double* parsca, const double* dxp, int nsys, int e) {
@@ -859,17 +853,8 @@ struct TfRowsBT {
 // The row requests of the walks are prefetches: they must be *issued* where they are written, one
 // node ahead of their use.  TF_PIN keeps the compiler from sinking them towards the use (a
 // memory clobber: loads and stores keep their side of it, the wait stays at the use).
-#ifndef TF_PIN
-#define TF_PIN 1                   // (config 3 +0.5 %, config 5 +3 %, 8 members +0.4 %: profiles/r03_ab_runs.txt)
-#endif
-#if TF_PIN
+// (config 3 +0.5 %, config 5 +3 %, 8 members +0.4 %: profiles/r03_ab_runs.txt)
 #define TF_PIN_REQUESTS() asm volatile("" ::: "memory")
-#else
-#define TF_PIN_REQUESTS() do {} while (0)
-#endif
-#ifndef TF_PREFETCH_DEEP
-#define TF_PREFETCH_DEEP(spike) 0
-#endif
 #ifndef TF_BACKSUB_DEPTH
 #define TF_BACKSUB_DEPTH 3
 #endif
@@ -893,12 +878,9 @@ constexpr int tf_ring_depth(int nd, int other = 40) {
 // h = mI: the up half is empty and everything reduces to the one-sided form.  So do solvers whose
 // chunks fill the GPU anyway (a.twist = 0: more than TF_TWIST_MAX_CHUNKS; there the second walk
 // only adds the middle system: 8 members per GPU -3 %, config 5 -1.5 %).
-#ifndef TF_TWIST
-#define TF_TWIST 1
-#endif
 template <int B, int MP>
 TF_DEVICE int tf_twist_h(int mI, int enabled) {
-    return (TF_TWIST && enabled && MP * B <= 6 && mI >= 4 * MP) ? (mI + 1) / 2 : mI;
+    return (enabled && MP * B <= 6 && mI >= 4 * MP) ? (mI + 1) / 2 : mI;
 }
 
 // ---- the separator equations, assembled by the walks themselves ---------------
@@ -1211,14 +1193,19 @@ TF_DEVICE void tfk_chunk_body(const TfLevelArgs& a, int pg, double* ylds = nullp
     };
     // columns c < 0 only occur for the first MP local rows (jl + d < 0); there the
     // window slot q equals jl (pivot 0), so `c = q + d < 0` is exactly that case.
-    constexpr bool DEEP = TF_PREFETCH_DEEP(SPIKE);
-    Pre pre0 = {}, pre1 = {};
-    request(0, pre0);
-    if (DEEP) request(1, pre1);
+    // (rows in flight ahead of the walk: one.  Two measured slower for blocks, and
+    // four for scalar models bought nothing -- config 2 19 973 -> 19 693 steps/s, N = 2e5 9 836 -> 8 457,
+    // profiles/r04_ab_runs.txt: their walk is the dependent chain of a node's division and FMAs, not
+    // the latency of its load)
+    constexpr int PD = 1;
+    Pre pre[PD] = {};
+#pragma unroll
+    for (int d = 0; d < PD; ++d) request(d, pre[d]);
     auto fetch = [&](int q, int jl) {              // jl == next_row: rows are taken in order
-        install(q, jl, pre0);
-        if (DEEP) { pre0 = pre1; request(jl + 2, pre1); }
-        else request(jl + 1, pre0);
+        install(q, jl, pre[0]);
+#pragma unroll
+        for (int d = 0; d + 1 < PD; ++d) pre[d] = pre[d + 1];
+        request(jl + PD, pre[PD - 1]);
         TF_PIN_REQUESTS();                           // (the loads leave here, whatever the scheduler would like)
     };
 
