@@ -223,8 +223,8 @@ def scheme_api_rate(model, cfg, N, scheme_name, dt, steps=20):
     (informational; the timed region above uses the ensemble C-ABI loop)."""
     from triflow_amd import schemes, workloads
     name, fd, pars, _, _ = workloads.config_inputs(cfg, N)
-    scheme = {"ROS2": schemes.ROS2, "Theta": schemes.Theta, "BDF2": schemes.BDF2,
-              "RODASPR": lambda m: schemes.RODASPR(m, time_stepping=False)}[scheme_name](model)
+    adaptive = {n: (lambda m, n=n: getattr(schemes, n)(m, time_stepping=False)) for n in ("ROS3PRw", "ROS3PRL", "RODASPR")}
+    scheme = dict({"ROS2": schemes.ROS2, "Theta": schemes.Theta, "BDF2": schemes.BDF2}, **adaptive)[scheme_name](model)
     fields, t = model.fields_template(**fd), 0.0
     for _ in range(3):
         t, fields = scheme(t, fields, dt, pars)

@@ -77,6 +77,7 @@ void launch(Module*, int kernel, unsigned gx, unsigned gy, unsigned block,
         for (unsigned y = 0; y < gy; ++y) for (int64_t t = 0; t < nthreads; ++t) tfk_sweep_body<false>(a, (int)t, (int)y); } break;
     case TFK_SWEEP_F_STAGE: { const auto& a = *(const TfSweepArgs*)args;
         for (unsigned y = 0; y < gy; ++y) for (int64_t t = 0; t < nthreads; ++t) tfk_sweep_body<false, true>(a, (int)t, (int)y); } break;
+    case TFK_SWEEP_F_STAGE_RHS_N:
     case TFK_SWEEP_F_STAGE_RHS: { const auto& a = *(const TfSweepArgs*)args;
         for (unsigned y = 0; y < gy; ++y) for (int64_t t = 0; t < nthreads; ++t) tfk_sweep_body<false, true, false, false, true, TF_STAGE_SEG>(a, (int)t, (int)y); } break;
     case TFK_SWEEP_FJ_BDF2: { const auto& a = *(const TfSweepArgs*)args;
@@ -96,7 +97,7 @@ void launch(Module*, int kernel, unsigned gx, unsigned gy, unsigned block,
         for (int64_t i = 0; i < a.n; ++i) tfk_vec_elem(a, i); } break;
     case TFK_VEC_MAXABS: { const auto& a = *(const TfVecArgs*)args;
         double m = *a.red;
-        for (int64_t i = 0; i < a.n; ++i) { double v = a.op == TF_VEC_MAXRATIO ? tf_vec_ratio(a, i) : tf_vec_err(a, i); m = (v > m || v != v) ? v : m; }
+        for (int64_t i = 0; i < a.n; ++i) { double v = a.op == TF_VEC_MAXRATIO ? tf_vec_ratio(a, i) : (a.op == TF_VEC_SUM_ERR ? tf_vec_sum_err(a, i) : tf_vec_err(a, i)); m = (v > m || v != v) ? v : m; }
         *a.red = m; } break;
     case TFK_BERR: { const auto& a = *(const TfBerrArgs*)args;
         double m = *a.red;

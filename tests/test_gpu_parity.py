@@ -463,15 +463,21 @@ def test_walks_assemble_the_separator_rows(cfg, sch, N, nsys, monkeypatch):
     assert np.isfinite(out[0]).all() and err <= 1e-10, err
 
 
-@pytest.mark.parametrize("name,N,periodic", [("M3_film", 3001, True), ("M3_film", 2003, False), ("bivar", 1501, False)])
-def test_split_factorisation_walk_equals_one_wavefront(name, N, periodic, monkeypatch):
+@pytest.mark.parametrize("name,N,periodic,opt", [("M3_film", 3001, True, None), ("M3_film", 2003, False, None),
+                                                 ("bivar", 1501, False, None), ("M3_film", 3001, True, "-O1")])
+def test_split_factorisation_walk_equals_one_wavefront(name, N, periodic, opt, monkeypatch):
     """tfk_l1_factor* by two wavefronts per 64 chunks and direction (one eliminates the band, the
     other carries the spike columns and the first right-hand side with the pivot blocks published
     in LDS; TF_L1_SPLIT_MODEL) does the arithmetic of the one-wavefront walk: the same products in
     the same order -- solutions equal to the last bits, with the stored spike response and with
-    the second elimination, and in steps whose first solve rides with the factorisation."""
+    the second elimination, and in steps whose first solve rides with the factorisation.  The grids
+    have ragged chunks (lanes of a wavefront with trip counts that differ by one: the two wavefronts
+    of a walk meet at one barrier per pivot, and the per-lane slots keep their parity whatever the
+    compiler makes of the loops: also at -O1)."""
     from triflow_amd import compilers
     from triflow_amd.ensemble import Ensemble
+    if opt:
+        monkeypatch.setattr(compilers, "HIPCC_FLAGS", [opt] + [f for f in compilers.HIPCC_FLAGS if not f.startswith("-O")])
     rng = np.random.default_rng(17)
     fd = corpus.synthetic_fields(name, N, seed=5, periodic=periodic, length=N * 5e-3)
     pars = corpus.synthetic_pars(name, N, periodic)

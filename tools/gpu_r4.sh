@@ -1,5 +1,5 @@
 #!/bin/bash
-# The GPU calls of round 4, one stage per call: gpurun -- bash tools/gpu_r4.sh <stage>   (stages: a b c d e f g)
+# The GPU calls of round 4, one stage per call: gpurun -- bash tools/gpu_r4.sh <stage>   (stages: a b c d e f g h)
 # Every stage writes under gpurun_out/; profiles/r04_ab_runs.txt and the other r04_* files quote them.
 case "$1" in
 a)
@@ -82,5 +82,14 @@ g)
     timeout -k 10 300 python3 tools/gpu_small_n.py > $O/small_n.txt 2>&1; tail -8 $O/small_n.txt
     bash tools/gpu_ab.sh r4g_cfg3 "" ""
     ;;
-*) echo "usage: $0 <a|b|c|d|e|f|g>"; exit 2;;
+h)
+    # stage passes with a compile-time number of stage vectors; the split walk at -O1
+    O=gpurun_out/r4h; mkdir -p $O
+    python3 -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "steps_golden or fused_stage or split_factorisation or row_monitor or simulation" > $O/pytest.log 2>&1; tail -4 $O/pytest.log
+    grep -q "failed" $O/pytest.log && exit 1
+    bash tools/gpu_ab.sh r4h_rodaspr "--scheme RODASPR" ""
+    bash tools/gpu_ab.sh r4h_ros3prl "--scheme ROS3PRL" ""
+    bash tools/gpu_ab.sh r4h_cfg3 "" ""
+    ;;
+*) echo "usage: $0 <a|b|c|d|e|f|g|h>"; exit 2;;
 esac

@@ -132,6 +132,7 @@ struct TfVecArgs {                 // elementwise plane algebra
     const double* x[TF_MAX_TERMS];
     double c[TF_MAX_TERMS];
     double* red;                   // reduction target (max-norm)
+    double c2[TF_MAX_TERMS];       // TF_VEC_SUM_ERR: the coefficients of the error estimate
 };
 
 struct TfPermArgs {                // natural order <-> partition-interleaved
@@ -334,7 +335,7 @@ enum TfKernel {
     TFK_TOP_FACTOR, TFK_TOP_SOLVE, TFK_BERR, TFK_DIFFNORM, TFK_L1_FACTOR_RHS, TFK_SWEEP_F_STAGE,
     TFK_CR_FACTOR, TFK_CR_FWD, TFK_CR_BWD, TFK_POKE, TFK_SWEEP_FJ_THETA, TFK_SWEEP_FJ_BDF2, TFK_SPMV_MON, TFK_GATHER,
     TFK_SWEEP_F_STAGE_RHS, TFK_L1_FWD2, TFK_L1_BACKSUB_U, TFK_CR_TAIL, TFK_L1_FWD2_BACKSUB, TFK_TINY_FACTOR, TFK_TINY_SOLVE,
-    TFK_S_FWD, TFK_S_BWD, TFK_COUNT
+    TFK_S_FWD, TFK_S_BWD, TFK_SWEEP_F_STAGE_RHS_N, TFK_COUNT
 };
 #define TF_KERNEL_NAMES { \
     "tfk_sweep_f", "tfk_sweep_fj", "tfk_spmv", "tfk_vec", "tfk_vec_maxabs", "tfk_perm", "tfk_dirichlet", \
@@ -343,4 +344,4 @@ enum TfKernel {
     "tfk_top_factor", "tfk_top_solve", "tfk_berr", "tfk_diffnorm", "tfk_l1_factor_rhs", "tfk_sweep_f_stage", \
     "tfk_cr_factor", "tfk_cr_fwd", "tfk_cr_bwd", "tfk_poke", "tfk_sweep_fj_theta", "tfk_sweep_fj_bdf2", \
     "tfk_spmv_mon", "tfk_gather", "tfk_sweep_f_stage_rhs", "tfk_l1_fwd2", "tfk_l1_backsub_u", "tfk_cr_tail", \
-    "tfk_l1_fwd2_backsub", "tfk_tiny_factor", "tfk_tiny_solve", "tfk_s_fwd", "tfk_s_bwd" }
+    "tfk_l1_fwd2_backsub", "tfk_tiny_factor", "tfk_tiny_solve", "tfk_s_fwd", "tfk_s_bwd", "tfk_sweep_f_stage_rhs_n" }

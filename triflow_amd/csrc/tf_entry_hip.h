@@ -79,6 +79,18 @@ __global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_sweep_f_stage(TfSweepArgs 
 __global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_sweep_f_stage_rhs(TfSweepArgs a) {
     tfk_sweep_body<false, true, false, false, true, TF_STAGE_SEG>(a, TF_GID, blockIdx.y);
 }
+// ... for the later stages of the 3-, 4- and 6-stage schemes: the number of stage vectors as a
+// compile-time constant (tfk_sweep_body NTERMS).  A kernel of its own: the five-term path takes
+// 200 registers, which the two-stage scheme's pass (one term, 144) should not pay for.
+__global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_sweep_f_stage_rhs_n(TfSweepArgs a) {
+    switch (a.nterms) {
+    case 2: tfk_sweep_body<false, true, false, false, true, TF_STAGE_SEG, 2>(a, TF_GID, blockIdx.y); break;
+    case 3: tfk_sweep_body<false, true, false, false, true, TF_STAGE_SEG, 3>(a, TF_GID, blockIdx.y); break;
+    case 4: tfk_sweep_body<false, true, false, false, true, TF_STAGE_SEG, 4>(a, TF_GID, blockIdx.y); break;
+    case 5: tfk_sweep_body<false, true, false, false, true, TF_STAGE_SEG, 5>(a, TF_GID, blockIdx.y); break;
+    default: tfk_sweep_body<false, true, false, false, true, TF_STAGE_SEG>(a, TF_GID, blockIdx.y);
+    }
+}
 __global__ void TF_SWEEP_ATTR __launch_bounds__(TF_SWEEP_BLOCK) tfk_sweep_fj(TfSweepArgs a) {
     tfk_sweep_body<true>(a, TF_GID, blockIdx.y);
 }
@@ -125,7 +137,7 @@ __global__ void __launch_bounds__(256) tfk_vec_maxabs(TfVecArgs a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     double m = 0.0;
     for (int64_t i = TF_GID; i < a.n; i += stride) {
-        const double v = a.op == TF_VEC_MAXRATIO ? tf_vec_ratio(a, i) : tf_vec_err(a, i);
+        const double v = a.op == TF_VEC_MAXRATIO ? tf_vec_ratio(a, i) : (a.op == TF_VEC_SUM_ERR ? tf_vec_sum_err(a, i) : tf_vec_err(a, i));
         m = (v > m || v != v) ? v : m;            // NaN wins, like np.linalg.norm(inf)
     }
     unsigned long long bits = (unsigned long long)__double_as_longlong(m);

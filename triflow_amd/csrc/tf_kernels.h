@@ -162,8 +162,11 @@ struct TfJUniform {
 // 1. F / F+J stencil sweep                       (compilers.py:227-332)
 // ===========================================================================
 // grid: x over chunks (all systems), y over segments of TF_SEG nodes.
+// NTERMS > 0 (stage forms): the number of stage vectors k_j is a compile-time constant, so that the
+// loads of a node's k_j are all issued before the first is used (with the run-time loop they went one
+// after the other: the stage pass of RODASPR's later stages ran at 2.8 TB/s, profiles/r04_ab_runs.txt)
 template <bool WITH_J, bool STAGE = false, bool THETA = false, bool BDF = false, bool STAGE_RHS = false,
-          int SEG = TF_SEG>
+          int SEG = TF_SEG, int NTERMS = 0>
 TF_DEVICE void tfk_sweep_body(const TfSweepArgs& a, int pg, int seg) {
     const TfLayout& L = a.L;
     if (pg >= L.Ptot) return;
@@ -192,6 +195,16 @@ TF_DEVICE void tfk_sweep_body(const TfSweepArgs& a, int pg, int seg) {
         const int64_t q = (int64_t)f * L.plane +
             ((ii >= 0 && ii < len) ? tf_idx(L, pg, ii) : tf_nbr(L, e, p, len, 0, ii));
         const double u = a.fields[q];
+        if constexpr (NTERMS > 0) {
+            double kk[NTERMS];
+#pragma unroll
+            for (int t = 0; t < NTERMS; ++t) kk[t] = a.kx[t][q];
+            double acc = a.kc[0] * kk[0], g = a.gc[0] * kk[0];
+#pragma unroll
+            for (int t = 1; t < NTERMS; ++t) { acc = acc + a.kc[t] * kk[t]; g = g + a.gc[t] * kk[t]; }
+            v = g;
+            return u + acc;
+        }
         double k = a.kx[0][q];
         double acc = a.kc[0] * k, g = a.gc[0] * k;
         for (int t = 1; t < a.nterms; ++t) { k = a.kx[t][q]; acc = acc + a.kc[t] * k; g = g + a.gc[t] * k; }
@@ -455,6 +468,8 @@ enum TfVecOp {
     TF_VEC_ADD = 6,        // out = x0 + x1
     TF_VEC_RESID = 7,      // out = (x0 - x1) + x2          r = b - x + c J x
     TF_VEC_MAXRATIO = 8,   // red = max |x0| / (|x1| + |x2| + |x3|)   componentwise backward error
+    TF_VEC_SUM_ERR = 9,    // TF_VEC_SUM and, on its result, TF_VEC_MAXABS with the coefficients c2: the new
+                           // state and the embedded error estimate of an adaptive Rosenbrock step in one pass
 };
 
 TF_DEVICE double tf_vec_sum(const TfVecArgs& a, int64_t i) {
@@ -472,6 +487,16 @@ TF_DEVICE double tf_vec_ratio(const TfVecArgs& a, int64_t i) {
 TF_DEVICE double tf_vec_err(const TfVecArgs& a, int64_t i) {
     const double acc = tf_vec_sum(a, i);
     return tf_abs(a.base ? a.base[i] - (a.base[i] + acc) : acc);
+}
+
+// TF_VEC_SUM_ERR: out = base + sum c x (tfk_vec_elem, TF_VEC_SUM), returns |out - (out + sum c2 x)| (tf_vec_err
+// with the new state as base): the two kernels' operations in their order
+TF_DEVICE double tf_vec_sum_err(const TfVecArgs& a, int64_t i) {
+    double acc = a.c[0] * a.x[0][i], acc2 = a.c2[0] * a.x[0][i];
+    for (int t = 1; t < a.nterms; ++t) { acc = acc + a.c[t] * a.x[t][i]; acc2 = acc2 + a.c2[t] * a.x[t][i]; }
+    const double nu = a.base[i] + acc;
+    a.out[i] = nu;
+    return tf_abs(nu - (nu + acc2));
 }
 
 TF_DEVICE void tfk_vec_elem(const TfVecArgs& a, int64_t i) {

@@ -46,11 +46,15 @@ void step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns, con
         else s->solve(s->Wrhs.p, s->K[i].p);
     }
     for (int j = 0; j < ns; ++j) { ks[j] = s->K[j].p; cs[j] = b[j]; }
-    if (!s->take_update_done()) s->vec(TF_VEC_SUM, U, Uin, ns, ks, cs);   // U + sum_i b_i k_i
+    const bool updated = s->take_update_done();
     if (b_pred && want_err) {
+        // the new state U + sum_i b_i k_i and ||U+ - (U+ + sum b_pred k)||_inf: one pass over the stages
+        // (an adaptive step never has its update inside the back-substitution: request_update above)
         s->zero(s->red.p, sizeof(double));
-        for (int j = 0; j < ns; ++j) cs[j] = b_pred[j];
-        s->vec(TF_VEC_MAXABS, nullptr, U, ns, ks, cs);             // ||U - (U + sum b_pred k)||_inf
+        if (!updated) s->vec(TF_VEC_SUM_ERR, U, Uin, ns, ks, cs, -1, 0, b_pred);
+        else s->vec(TF_VEC_MAXABS, nullptr, U, ns, ks, b_pred);
+    } else if (!updated) {
+        s->vec(TF_VEC_SUM, U, Uin, ns, ks, cs);                    // U + sum_i b_i k_i
     }
     if (hook_after) { s->apply_dirichlet(U, true); s->mark_hooked(dst); }
 }

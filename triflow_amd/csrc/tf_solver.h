@@ -129,7 +129,7 @@ using namespace tfrt;
 // enum values of tf_kernels.h (kept in sync by tests/test_abi.py)
 enum {
     TF_VEC_SUM = 0, TF_VEC_LIN2 = 1, TF_VEC_THETA_RHS = 2, TF_VEC_MAXABS = 3, TF_VEC_COPY = 4,
-    TF_VEC_BDF2_RHS = 5, TF_VEC_ADD = 6, TF_VEC_RESID = 7, TF_VEC_MAXRATIO = 8
+    TF_VEC_BDF2_RHS = 5, TF_VEC_ADD = 6, TF_VEC_RESID = 7, TF_VEC_MAXRATIO = 8, TF_VEC_SUM_ERR = 9
 };
 
 struct tf_model {
@@ -382,7 +382,7 @@ struct tf_solver {
     }
 
     // ------------------------------------------------------ elementary steps
-    void vec(int op, double* out, const double* base, int nterms, const double* const* xs, const double* cs, int64_t n = -1, int red_slot = 0);
+    void vec(int op, double* out, const double* base, int nterms, const double* const* xs, const double* cs, int64_t n = -1, int red_slot = 0, const double* cs2 = nullptr);
 
     void perm(int mode, const double* src, double* dst, int ncomp);
     void ensure_staging(size_t count);

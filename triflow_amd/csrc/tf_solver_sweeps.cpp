@@ -1,14 +1,14 @@
 // tf_solver: elementary steps -- stencil sweeps, J @ v, vector algebra, declarative hooks (see tf_solver.h)
 #include "tf_solver.h"
 
-void tf_solver::vec(int op, double* out, const double* base, int nterms, const double* const* xs, const double* cs, int64_t n, int red_slot) {
+void tf_solver::vec(int op, double* out, const double* base, int nterms, const double* const* xs, const double* cs, int64_t n, int red_slot, const double* cs2) {
     TfVecArgs a;
     std::memset(&a, 0, sizeof(a));
     a.n = n < 0 ? vecn() : n;
     a.nterms = nterms; a.op = op; a.out = out; a.base = base; a.red = red.p + red_slot;
-    for (int t = 0; t < nterms; ++t) { a.x[t] = xs[t]; a.c[t] = cs ? cs[t] : 1.0; }
+    for (int t = 0; t < nterms; ++t) { a.x[t] = xs[t]; a.c[t] = cs ? cs[t] : 1.0; a.c2[t] = cs2 ? cs2[t] : 0.0; }
     unsigned grid = std::min<unsigned>(cdiv(a.n, 256), 2048u);
-    launch((op == TF_VEC_MAXABS || op == TF_VEC_MAXRATIO) ? TFK_VEC_MAXABS : TFK_VEC, std::max(grid, 1u), 1, 256, &a, sizeof(a));
+    launch((op == TF_VEC_MAXABS || op == TF_VEC_MAXRATIO || op == TF_VEC_SUM_ERR) ? TFK_VEC_MAXABS : TFK_VEC, std::max(grid, 1u), 1, 256, &a, sizeof(a));
 }
 
 void tf_solver::perm(int mode, const double* src, double* dst, int ncomp) {
@@ -189,7 +189,7 @@ void tf_solver::stage_rhs(const double* Uin, int nterms, const double* const* ks
     a.dx = dx.p; a.xcoord = xcoord.p; a.F = Wstage.p; a.Jv = Jv.p;
     a.stage_rhs = y; a.cF = dt; a.cA = dt;
     unsigned gx = sweep_gx(), gy = cdiv(L1.M, TF_STAGE_SEG);
-    launch(TFK_SWEEP_F_STAGE_RHS, gx, gy, spec.sweep_block, &a, sizeof(a));
+    launch(nterms >= 2 && nterms <= 5 ? TFK_SWEEP_F_STAGE_RHS_N : TFK_SWEEP_F_STAGE_RHS, gx, gy, spec.sweep_block, &a, sizeof(a));
 }
 
 void tf_solver::spmv_stage(int nterms, const double* const* vx, const double* vc, const double* Fp, double cF, double cA, double* y, const double* monitor_rhs) {
