@@ -98,6 +98,8 @@ def _cpu_sample(job):
     model = Model(*workloads.model_args(name),
                   compiler=ora.fair_numpy_compiler if fair else ora.numpy_compiler)
     scheme = {"ROS2": ora.ROS2, "RODASPR": lambda m: ora.RODASPR(m, time_stepping=False),
+              "ROS3PRw": lambda m: ora.ROS3PRw(m, time_stepping=False),
+              "ROS3PRL": lambda m: ora.ROS3PRL(m, time_stepping=False),
               "Theta": ora.Theta, "BDF2": ora.BDF2}[scheme_name](model)
     fields = model.fields_template(**fd)
     hook = config_hook(cfg)

@@ -173,6 +173,15 @@ int tf_bdf2_release(tf_solver*, int64_t owner);      /* frees that history buffe
  * schemes keep the hooked copy): unless a step of this solver left it so, the boundary values are
  * written into slot `src` in place -- the one step function that modifies its input slot. */
 int tf_step_bdf2_from(tf_solver*, int32_t src, int32_t dst, int32_t prev, double dt);
+/* tf_step_row with the embedded error estimate left on the device, in reduction slot `err_slot`
+ * (1, 2 or 3), until tf_read_err fetches it (blocking; the failure flag is looked at as well).  For a
+ * driver of the adaptive schemes (triflow/core/schemes.py:176-238) that queues the first trial of the
+ * next call before it reads the estimate of the step it is about to return: the host's decision
+ * overlaps with the GPU's next step.  b_pred is required. */
+int tf_step_row_queued(tf_solver*, int32_t src, int32_t dst, double dt, int32_t stages,
+                       const double* alpha, const double* gamma, const double* b,
+                       const double* b_pred, int32_t hook_after, int32_t err_slot);
+int tf_read_err(tf_solver*, int32_t err_slot, double* err_out);
 /* One trial of the reference's universal step-doubling controller (schemes.py:33-66; it wraps
  * every scheme a Simulation builds, simulation.py:190-197) without a host round trip per
  * sub-step: a coarse step m*dt (src -> coarse), `nfine` fine steps dt (src -> tmp -> dst ...,

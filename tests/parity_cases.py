@@ -449,12 +449,16 @@ def check_adaptive_landing_reuse(backend):
     factorisation."""
     from triflow_amd import _capi
     calls = {"row": 0}
-    orig = _capi.DeviceSolver.step_row
+    orig, orig_q = _capi.DeviceSolver.step_row, _capi.DeviceSolver.step_row_queued
 
     def counting(self, *a, **k):
         calls["row"] += 1
         return orig(self, *a, **k)
-    _capi.DeviceSolver.step_row = counting
+
+    def counting_q(self, *a, **k):
+        calls["row"] += 1
+        return orig_q(self, *a, **k)
+    _capi.DeviceSolver.step_row, _capi.DeviceSolver.step_row_queued = counting, counting_q
     try:
         for cfg, N, hook in ((3, 400, None), (1, 200, DEVICE_HOOKS["cfg1"]), (1, 200, HOOKS["cfg1"])):
             name, fd, pars, dt, _ = corpus.config_inputs(cfg, N)
@@ -481,8 +485,31 @@ def check_adaptive_landing_reuse(backend):
             else:
                 assert counts[0] < counts[1], counts           # fewer Rosenbrock steps
                 assert counts[1] - counts[0] >= 3, counts      # ... by one per call once the controller's step exceeds dt
+        # The first trial of the next call queued ahead of the read of this call's error estimate
+        # (ROW_general.QUEUE_NEXT_TRIAL): the same steps, earlier -- bit for bit the states of the
+        # controller that launches every trial when it needs it, also when the caller changes dt, hands
+        # in a copy of the container, or other parameters (the queued step is dropped)
+        name, fd, pars, dt, _ = corpus.config_inputs(3, 400)
+        m = device_model(name, backend)
+        out = []
+        for queue in (True, False):
+            scheme = schemes.RODASPR(m, tol=1e-1)
+            scheme.QUEUE_NEXT_TRIAL = queue
+            f, t, p = m.fields_template(**fd), 0.3, pars
+            states = []
+            with np.errstate(all="ignore"):
+                for k in range(22):
+                    if k == 14:
+                        f = f.copy()                     # another container: nothing queued applies
+                    if k == 17:
+                        p = dict(p, We=0.02)             # other parameters
+                    t, f = scheme(t, f, dt if k < 10 or k >= 12 else 0.5 * dt, p)
+                    states.append(f.uflat.copy())
+            out.append(states)
+        for a, b in zip(*out):
+            assert np.isfinite(a).all() and np.array_equal(a, b)
     finally:
-        _capi.DeviceSolver.step_row = orig
+        _capi.DeviceSolver.step_row, _capi.DeviceSolver.step_row_queued = orig, orig_q
     # Simulation -> Theta on the constant-matrix model: one factorisation serves every landing step
     name, fd, pars, dt, _ = corpus.config_inputs(2, 2000)
     m = device_model(name, backend)

@@ -744,3 +744,27 @@ def test_scalar_solve_in_two_launches(name, N, monkeypatch):
 
 def test_theta_bdf2_monitor():
     pc.check_theta_bdf2_monitor(HIP)
+
+
+def test_scalar_solve_in_two_launches_ensemble(monkeypatch):
+    """... with several systems in one solver (a workgroup per level-2 chunk and system, one counter per
+    system): three members of the diffusion model with different coefficients, Theta and ROS2 steps, the
+    two-launch solve against the six launches, bit for bit."""
+    from triflow_amd.ensemble import Ensemble
+    name, fd, pars, dt, _ = corpus.config_inputs(2, 20011)
+    m = pc.device_model(name, HIP)
+    fields = {"U": np.stack([fd["U"] * (1 + 0.1 * e) for e in range(3)])}
+    p3 = dict(pars, k=np.array([1e-3, 2e-3, 5e-4]))
+    for sch in ("Theta", "ROS2"):
+        out = {}
+        for fuse in ("1", "0"):
+            monkeypatch.setenv("TRIFLOW_S_FUSE", fuse)
+            ens = Ensemble(m, fd["x"], fields, p3, True, scheme=sch, nstate=2, refine=0)
+            assert len(ens.solver.describe()["chunks"]) == 3
+            for _ in range(4):
+                ens.step(dt)
+            ens.sync()
+            out[fuse] = ens.state().copy()
+            ens.close()
+        assert np.isfinite(out["1"]).all() and np.array_equal(out["1"], out["0"]), sch
+        assert np.abs(out["1"][0, 0] - out["1"][0, 1]).max() > 0        # (the members do differ)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# The GPU calls of round 4, one stage per call: gpurun -- bash tools/gpu_r4.sh <stage>   (stages: a b c d e f g h)
+# The GPU calls of round 4, one stage per call: gpurun -- bash tools/gpu_r4.sh <stage>   (stages: a b c d e f g h i)
 # Every stage writes under gpurun_out/; profiles/r04_ab_runs.txt and the other r04_* files quote them.
 case "$1" in
 a)
@@ -91,5 +91,13 @@ h)
     bash tools/gpu_ab.sh r4h_ros3prl "--scheme ROS3PRL" ""
     bash tools/gpu_ab.sh r4h_cfg3 "" ""
     ;;
-*) echo "usage: $0 <a|b|c|d|e|f|g|h>"; exit 2;;
+i)
+    # the next trial queued ahead of the error read; new state + error estimate in one pass
+    O=gpurun_out/r4i; mkdir -p $O
+    python3 -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "landing or scalar_solve or steps_golden or simulation or errors" > $O/pytest.log 2>&1; tail -4 $O/pytest.log
+    grep -q "failed" $O/pytest.log && exit 1
+    timeout -k 10 600 python3 tools/gpu_simulation_rate.py --iters 20 > $O/sim_cfg3.txt 2>&1; tail -4 $O/sim_cfg3.txt
+    timeout -k 10 300 python3 tools/gpu_simulation_rate.py --config 2 --iters 20 > $O/sim_cfg2.txt 2>&1; tail -4 $O/sim_cfg2.txt
+    ;;
+*) echo "usage: $0 <a|b|c|d|e|f|g|h|i>"; exit 2;;
 esac

@@ -74,6 +74,9 @@ SIGNATURES = {
     "tf_step_row": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_int32,
                               c_double_p, c_double_p, c_double_p, c_double_p, C.c_int32,
                               c_double_p]),
+    "tf_step_row_queued": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_int32,
+                                     c_double_p, c_double_p, c_double_p, c_double_p, C.c_int32, C.c_int32]),
+    "tf_read_err": (C.c_int, [C.c_void_p, C.c_int32, c_double_p]),
     "tf_step_bdf2": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double]),
     "tf_bdf2_reset": (C.c_int, [C.c_void_p]),
     "tf_step_bdf2_from": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double]),
@@ -362,6 +365,18 @@ class DeviceSolver:
                       _dptr(gamma), _dptr(b), _dptr(bp) if bp is not None else None,
                       int(hook_after), C.byref(err) if want_err else None)
         return np.float64(err.value) if (want_err and bp is not None) else None
+
+    def step_row_queued(self, src, dst, dt, alpha, gamma, b, b_pred, hook_after=False, err_slot=1):
+        """The same step; its embedded error estimate stays on the device (reduction slot ``err_slot``)
+        until :meth:`read_err` fetches it."""
+        alpha, gamma, b, bp = _f64(alpha), _f64(gamma), _f64(b), _f64(b_pred)
+        self.lib.call("tf_step_row_queued", self.handle, src, dst, float(dt), b.size, _dptr(alpha),
+                      _dptr(gamma), _dptr(b), _dptr(bp), int(hook_after), int(err_slot))
+
+    def read_err(self, err_slot):
+        err = C.c_double(0.0)
+        self.lib.call("tf_read_err", self.handle, int(err_slot), C.byref(err))
+        return np.float64(err.value)
 
     def step_bdf2(self, src, dst, dt, owner=0, continuing=True):
         """``owner`` 0: the solver's own history (a caller that owns the solver); otherwise the

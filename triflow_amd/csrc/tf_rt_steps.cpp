@@ -20,7 +20,8 @@ void step_theta(tf_solver* s, int32_t src, int32_t dst, double dt, double theta)
 // Rosenbrock-Wanner fixed step, reference schemes.py:142-174.  With b_pred the maximum of
 // |U - U_pred| is left in red[0] (the caller reads it).
 void step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns, const double* alpha,
-              const double* gamma, const double* b, const double* b_pred, bool hook_after, bool want_err) {
+              const double* gamma, const double* b, const double* b_pred, bool hook_after, bool want_err,
+              int err_slot = 0) {
     require(ns >= 1 && ns <= 6, "tf_step_row: 1 <= s <= 6");
     require(src != dst, "tf_step_row: src and dst slots must differ");
     double* U = s->st(dst);
@@ -50,9 +51,9 @@ void step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns, con
     if (b_pred && want_err) {
         // the new state U + sum_i b_i k_i and ||U+ - (U+ + sum b_pred k)||_inf: one pass over the stages
         // (an adaptive step never has its update inside the back-substitution: request_update above)
-        s->zero(s->red.p, sizeof(double));
-        if (!updated) s->vec(TF_VEC_SUM_ERR, U, Uin, ns, ks, cs, -1, 0, b_pred);
-        else s->vec(TF_VEC_MAXABS, nullptr, U, ns, ks, b_pred);
+        s->zero(s->red.p + err_slot, sizeof(double));
+        if (!updated) s->vec(TF_VEC_SUM_ERR, U, Uin, ns, ks, cs, -1, err_slot, b_pred);
+        else s->vec(TF_VEC_MAXABS, nullptr, U, ns, ks, b_pred, -1, err_slot);
     } else if (!updated) {
         s->vec(TF_VEC_SUM, U, Uin, ns, ks, cs);                    // U + sum_i b_i k_i
     }
@@ -134,6 +135,33 @@ int tf_step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns,
         }
         s->check_status();
     }
+    TF_API_END
+}
+
+// The same step with its embedded error estimate left on the device, in reduction slot `err_slot`
+// (1 ... 3: slot 0 belongs to the blocking forms), and read later by tf_read_err: a driver that has the
+// next step queued before it looks at this one's estimate keeps the GPU busy while it decides
+// (schemes.ROW_general: the accepted trial of a call and the first trial of the next one).
+int tf_step_row_queued(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns,
+                       const double* alpha, const double* gamma, const double* b,
+                       const double* b_pred, int32_t hook_after, int32_t err_slot) {
+    TF_API_BEGIN
+    require(s && alpha && gamma && b && b_pred, "null argument");
+    require(ns >= 1 && ns <= 6, "tf_step_row_queued: 1 <= s <= 6");
+    require(err_slot >= 1 && err_slot <= 3, "tf_step_row_queued: err_slot is 1, 2 or 3");
+    s->prepare_step(gamma[0] * dt);
+    step_row(s, src, dst, dt, ns, alpha, gamma, b, b_pred, hook_after != 0, true, err_slot);
+    if (hook_after) s->mark_hooked(dst); else s->slot_written(dst);
+    TF_API_END
+}
+int tf_read_err(tf_solver* s, int32_t err_slot, double* err_out) {
+    TF_API_BEGIN
+    require(s && err_out, "null argument");
+    require(err_slot >= 0 && err_slot <= 3, "tf_read_err: err_slot is 0 ... 3");
+    uint64_t bits = 0;
+    tfb::d2h(&bits, s->red.p + err_slot, sizeof(bits), s->stream);
+    std::memcpy(err_out, &bits, sizeof(double));
+    s->check_status();
     TF_API_END
 }
 

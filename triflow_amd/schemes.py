@@ -234,14 +234,19 @@ class ROW_general:
         return t, fields
 
     def _fixed_step(self, t, fields, dt, pars, hook=null_hook, hook_after=False,
-                    want_err=True):
+                    want_err=True, err_slot=None):
         """``schemes.py:142-174``; returns ``(t + dt, fields, err)`` with
         ``err = ||U - U_pred||_inf`` when the tableau has ``b_pred``.
         ``hook_after`` is the extra hook call of the fixed-step ``__call__``
-        (``schemes.py:137-140``)."""
+        (``schemes.py:137-140``).  ``err_slot``: the step is only queued, its estimate stays on
+        the device and ``err`` is a callable that fetches it (``tf_step_row_queued``)."""
         device_hook = _is_device_hook(hook)
 
         def launch(solver, src, dst):
+            if err_slot is not None:
+                solver.step_row_queued(src, dst, dt, self._alpha, self._gamma, self._b, self._b_pred,
+                                       hook_after=hook_after and device_hook, err_slot=err_slot)
+                return lambda: solver.read_err(err_slot)
             return solver.step_row(src, dst, dt, self._alpha, self._gamma, self._b,
                                    self._b_pred, hook_after=hook_after and device_hook,
                                    want_err=want_err and self._b_pred is not None)
@@ -260,6 +265,44 @@ class ROW_general:
     #: step's (with the closing hook applied): half the work per accepted ``dt`` of the default
     #: ``Simulation`` path (profiles/r04_default_user_path.txt).  Set to False for the literal sequence.
     REUSE_TRIAL_AS_LANDING = True
+
+    #: While the host looks at the error estimate of a trial the GPU would sit idle -- and in the steady
+    #: state of a smooth run the next thing it will be asked for is known: the same step from the state
+    #: this trial produced (the next call's first trial, ``dt`` the caller's).  That step is queued
+    #: *before* the estimate is read (``tf_step_row_queued``), and the next call takes it if it asks for
+    #: exactly that (same container, ``t``, ``dt``, parameters, hook); otherwise it is dropped.  Nothing
+    #: is returned unverified: every trial's estimate is read before the controller acts on it, in the
+    #: reference's order (profiles/r04_default_user_path.txt: 682 -> see there, accepted dt/s).
+    QUEUE_NEXT_TRIAL = True
+
+    def _trial(self, t, fields, dt, pars, hook, target):
+        """One trial of ``_variable_step``: ``_fixed_step`` -- taken from the step the previous call
+        queued ahead when it is that very step -- with the likely next one queued behind it."""
+        spec, self._spec = getattr(self, "_spec", None), None
+        usable = (self.QUEUE_NEXT_TRIAL and self.REUSE_TRIAL_AS_LANDING and self._recompute_target
+                  and self._b_pred is not None
+                  and (hook is null_hook or getattr(hook, "__name__", "") == "null_hook")
+                  and getattr(fields, "_device_backing", lambda: None)() is not None)
+        if not usable:
+            return self._fixed_step(t, fields, dt, pars, hook)
+        if spec is not None and spec["fields"] is fields and spec["t"] == t and spec["dt"] == dt \
+                and spec["pars"] is pars:
+            new_t, new_fields, fetch, slot = spec["new_t"], spec["new_fields"], spec["fetch"], spec["slot"]
+        else:
+            slot = 1
+            new_t, new_fields, fetch = self._fixed_step(t, fields, dt, pars, hook, err_slot=slot)
+        # the trial that would follow if this one is accepted and lands on the target with the
+        # controller's step still above the caller's dt: queued now, looked at by the next call
+        if new_t >= target and dt == getattr(self, "_call_dt", None) \
+                and abs((target - t) - dt) <= np.spacing(abs(target)):
+            nslot = 2 if slot == 1 else 1
+            nt, nf, nfetch = self._fixed_step(target, new_fields, dt, pars, hook, err_slot=nslot)
+            self._spec = dict(fields=new_fields, t=target, dt=dt, pars=pars, new_t=nt, new_fields=nf,
+                              fetch=nfetch, slot=nslot)
+        err = fetch()
+        if err > self._tol:
+            self._spec = None              # rejected: what was queued behind it started from a state nobody keeps
+        return new_t, new_fields, err
 
     def _landing_from_trial(self, new_fields, dt_used, t, target, pars, hook):
         if not self.REUSE_TRIAL_AS_LANDING or abs((target - t) - dt_used) > np.spacing(abs(target)):
@@ -289,12 +332,13 @@ class ROW_general:
                 fields.fill(U0 + (U1 - U0) * ((target - t0) / (t1 - t0)))
                 return target, fields
         start = 1e-6 if self._internal_dt is None else self._internal_dt
+        self._call_dt = dt
         dt = self._internal_dt = min(start, dt) if self._recompute_target else start
         while True:
             self._err = None
             while self._err is None or self._err > self._tol:
                 dt_used = dt
-                new_t, new_fields, self._err = self._fixed_step(t, fields, dt, pars, hook)
+                new_t, new_fields, self._err = self._trial(t, fields, dt, pars, hook, target)
                 log.debug("error: %s", self._err)
                 with np.errstate(divide="ignore"):      # err == 0 -> dt = inf, as in NumPy
                     dt = self._internal_dt = (self._safety_factor * dt
