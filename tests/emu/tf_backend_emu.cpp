@@ -61,6 +61,12 @@ Graph* capture_end(Stream*) { return nullptr; }
 void capture_abort(Stream*) {}
 void graph_launch(Graph*, Stream*) {}
 void graph_destroy(Graph*) {}
+struct Mailbox { char host[64]; };
+Mailbox* mailbox_create() { return new Mailbox(); }
+void mailbox_destroy(Mailbox* m) { delete m; }
+void mailbox_post(Mailbox* m, int at, const void* dev_src, size_t bytes, Stream*) { std::memcpy(m->host + at, dev_src, bytes); }
+void mailbox_mark(Mailbox*, Stream*) {}
+void mailbox_wait(Mailbox* m, void* dst, size_t bytes) { std::memcpy(dst, m->host, bytes); }
 Event* event_create() { return new Event(); }
 void event_destroy(Event* e) { delete e; }
 void event_record(Event*, Stream*) {}

@@ -30,6 +30,7 @@ N = fd["x"].size
 
 calls = dict(row=0, theta=0, norm=0, err_waits=0)
 _row, _theta, _norm = _capi.DeviceSolver.step_row, _capi.DeviceSolver.step_theta, _capi.DeviceSolver.diff_norms
+_rowq, _rerr = _capi.DeviceSolver.step_row_queued, _capi.DeviceSolver.read_err
 
 
 def step_row(self, *a, **k):
@@ -37,6 +38,16 @@ def step_row(self, *a, **k):
     if k.get("want_err", True) and (len(a) > 6 and a[6] is not None or k.get("b_pred") is not None):
         calls["err_waits"] += 1
     return _row(self, *a, **k)
+
+
+def step_row_queued(self, *a, **k):
+    calls["row"] += 1
+    return _rowq(self, *a, **k)
+
+
+def read_err(self, *a, **k):
+    calls["err_waits"] += 1
+    return _rerr(self, *a, **k)
 
 
 def step_theta(self, *a, **k):
@@ -50,6 +61,7 @@ def diff_norms(self, *a, **k):
 
 
 _capi.DeviceSolver.step_row, _capi.DeviceSolver.step_theta, _capi.DeviceSolver.diff_norms = step_row, step_theta, diff_norms
+_capi.DeviceSolver.step_row_queued, _capi.DeviceSolver.read_err = step_row_queued, read_err
 
 
 def solver_of(fields):

@@ -64,6 +64,16 @@ void capture_abort(Stream* s);
 void graph_launch(Graph* g, Stream* s);
 void graph_destroy(Graph* g);
 
+// A few bytes from the device to the host without waiting for what is queued behind them: `post` queues
+// the copy (page-locked target) and marks the spot in the stream, `wait` blocks until that spot is
+// reached -- not until the stream is empty, as d2h does -- and hands the bytes over (<= 64).
+struct Mailbox;
+Mailbox* mailbox_create();
+void mailbox_destroy(Mailbox* m);
+void mailbox_post(Mailbox* m, int at, const void* dev_src, size_t bytes, Stream* s);   // bytes land at offset `at`
+void mailbox_mark(Mailbox* m, Stream* s);
+void mailbox_wait(Mailbox* m, void* dst, size_t bytes);
+
 Event* event_create();
 void event_destroy(Event* e);
 void event_record(Event* e, Stream* s);

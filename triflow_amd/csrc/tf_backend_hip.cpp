@@ -274,6 +274,29 @@ void graph_destroy(Graph* g) {
     delete g;
 }
 
+struct Mailbox { char* host = nullptr; hipEvent_t ev; };
+Mailbox* mailbox_create() {
+    Mailbox* m = new Mailbox();
+    TF_HIP(hipHostMalloc((void**)&m->host, 64, hipHostMallocDefault));
+    std::memset(m->host, 0, 64);
+    TF_HIP(hipEventCreateWithFlags(&m->ev, hipEventDisableTiming));
+    return m;
+}
+void mailbox_destroy(Mailbox* m) {
+    if (!m) return;
+    (void)hipEventDestroy(m->ev);
+    (void)hipHostFree(m->host);
+    delete m;
+}
+void mailbox_post(Mailbox* m, int at, const void* dev_src, size_t bytes, Stream* s) {
+    TF_HIP(hipMemcpyAsync(m->host + at, dev_src, bytes, hipMemcpyDeviceToHost, s->s));
+}
+void mailbox_mark(Mailbox* m, Stream* s) { TF_HIP(hipEventRecord(m->ev, s->s)); }
+void mailbox_wait(Mailbox* m, void* dst, size_t bytes) {
+    TF_HIP(hipEventSynchronize(m->ev));
+    std::memcpy(dst, m->host, bytes);
+}
+
 Event* event_create() {
     Event* e = new Event();
     TF_HIP(hipEventCreate(&e->e));

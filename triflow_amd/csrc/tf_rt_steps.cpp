@@ -152,16 +152,24 @@ int tf_step_row_queued(tf_solver* s, int32_t src, int32_t dst, double dt, int32_
     s->prepare_step(gamma[0] * dt);
     step_row(s, src, dst, dt, ns, alpha, gamma, b, b_pred, hook_after != 0, true, err_slot);
     if (hook_after) s->mark_hooked(dst); else s->slot_written(dst);
+    // the estimate and the failure flag as they stand behind this step go to a page-locked mailbox:
+    // tf_read_err waits for this spot of the stream, not for what the caller queues after it
+    if (!s->err_box[err_slot]) s->err_box[err_slot] = tfb::mailbox_create();
+    tfb::mailbox_post(s->err_box[err_slot], 0, s->red.p + err_slot, sizeof(double), s->stream);
+    tfb::mailbox_post(s->err_box[err_slot], 8, s->status, sizeof(int), s->stream);
+    tfb::mailbox_mark(s->err_box[err_slot], s->stream);
     TF_API_END
 }
 int tf_read_err(tf_solver* s, int32_t err_slot, double* err_out) {
     TF_API_BEGIN
     require(s && err_out, "null argument");
-    require(err_slot >= 0 && err_slot <= 3, "tf_read_err: err_slot is 0 ... 3");
-    uint64_t bits = 0;
-    tfb::d2h(&bits, s->red.p + err_slot, sizeof(bits), s->stream);
-    std::memcpy(err_out, &bits, sizeof(double));
-    s->check_status();
+    require(err_slot >= 1 && err_slot <= 3 && s->err_box[err_slot], "tf_read_err: no step was queued with this err_slot");
+    char buf[16];
+    tfb::mailbox_wait(s->err_box[err_slot], buf, sizeof(buf));
+    std::memcpy(err_out, buf, sizeof(double));
+    int flag = 0;
+    std::memcpy(&flag, buf + 8, sizeof(int));
+    if (flag != 0) s->check_status();              // (reads the flag again behind everything queued, resets it, raises)
     TF_API_END
 }
 

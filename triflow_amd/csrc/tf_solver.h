@@ -169,6 +169,7 @@ struct tf_solver {
     DevBuf staging, normbuf;
     DevBuf red;            // reduction scalars
     int* status = nullptr;
+    tfb::Mailbox* err_box[4] = {nullptr, nullptr, nullptr, nullptr};   // tf_step_row_queued / tf_read_err
     std::vector<std::unique_ptr<Level>> levels;     // chunk levels; the last one has P == 1
     Level top;             // single-node system per ensemble member
     DevBuf topAinv;
@@ -329,6 +330,7 @@ struct tf_solver {
         if (csc_map) tfb::dev_free(csc_map);
         if (status) tfb::dev_free(status);
         if (sfuse_counter) tfb::dev_free(sfuse_counter);
+        for (auto* m : err_box) tfb::mailbox_destroy(m);
         if (dir_var) tfb::dev_free(dir_var);
         if (dir_node) tfb::dev_free(dir_node);
         delete fallback;
