@@ -285,9 +285,11 @@ class ROW_general:
                   and getattr(fields, "_device_backing", lambda: None)() is not None)
         if not usable:
             return self._fixed_step(t, fields, dt, pars, hook)
-        if spec is not None and spec["fields"] is fields and spec["t"] == t and spec["dt"] == dt \
-                and spec["pars"] is pars:
-            new_t, new_fields, fetch, slot = spec["new_t"], spec["new_fields"], spec["fetch"], spec["slot"]
+        # (dt "the same": a driver that lands on t + dt asks for target - t, the last call's dt give or
+        # take the rounding of the sum -- the tolerance of the landing step, REUSE_TRIAL_AS_LANDING)
+        if spec is not None and spec["fields"] is fields and spec["t"] == t and spec["pars"] is pars \
+                and abs(spec["dt"] - dt) <= np.spacing(abs(t + dt)):
+            new_t, new_fields, fetch, slot = t + dt, spec["new_fields"], spec["fetch"], spec["slot"]
         else:
             slot = 1
             new_t, new_fields, fetch = self._fixed_step(t, fields, dt, pars, hook, err_slot=slot)
