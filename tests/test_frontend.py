@@ -108,3 +108,14 @@ def test_fields_hook_idiom_writes_through():
     assert f.uflat[0] == 1 and f.uflat[-1] == 2
     f["grad"] = np.gradient(f["U"])                # post-process style new entry
     assert "grad" in f
+
+
+def test_block_size_limit_is_named_at_compile():
+    """b = (stencil half width) x (variables) > 16 is refused when the model is compiled, with a
+    message that names the limit (the reference accepts any size, model.py:138-150)."""
+    import pytest
+    from triflow_amd import Model
+    from triflow_amd.codegen import UnsupportedExpression
+    eqs = ["dxxxx%s + %s" % (v, w) for v, w in zip("ABCDGHKLM", "BCDGHKLMA")]
+    with pytest.raises(UnsupportedExpression, match=r"b = 2 x 9 = 18"):
+        Model(eqs, list("ABCDGHKLM"), None, None)

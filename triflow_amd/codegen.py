@@ -218,6 +218,12 @@ def lower_model(model, parvec_mask=0, seg=8, sweep_block=64):
         mp = 1          # purely local models still get the width-3 skeleton
     if nvar + nh > 16 or len(pars) > 16:
         raise UnsupportedExpression("too many fields / parameters for the HIP skeleton")
+    if mp * nvar > 16:
+        # (the reduced levels of the banded solver are written for blocks of up to 16 x 16: 8 or 16 lanes
+        # share a block row, tf_coop_hip.h; the reference takes any size, triflow/core/model.py:138-150)
+        raise UnsupportedExpression(
+            "the banded solver of the HIP back end handles b = (stencil half width) x (number of dependent "
+            "variables) <= 16; this model has b = %d x %d = %d" % (mp, nvar, mp * nvar))
     sparse = [int(k) for k in model._sparse_indices[0]]
     nnz = len(sparse)
     real_mp = (model._window_range - 1) // 2
