@@ -7,13 +7,12 @@
 // there + 2 190 block inversion + 1 000-1 260 stores (four divergent branches per entry, 64-bit
 // addresses per lane) + barrier; phase B 680 prologue + 650-750 products + 830 stores + barrier:
 // ~6 000 cycles for 6 pivots and 24 FMAs per lane, issued by a lone wavefront at one instruction per
-// 8-10 cycles -- the instruction count is the time (SQ counters: SALU = 0.66 x VALU, any instruction
-// active 0.30).  Here
+// 8-10 cycles (SQ counters: SALU = 0.66 x VALU, any instruction active 0.30).  Here
 //   * lane c of each half wavefront holds COLUMN c of the augmented block [L | D | U | y | I] of the
 //     node that goes, its b rows in b registers.  A pivot step is: the pivot and the b-1 multipliers
 //     by v_readlane (wave-uniform scalars), the reciprocal on them, one multiply and b-1 FMAs with
-//     scalar operands -- ~23 instructions against ~45, no ds_bpermute, no DPP (nothing on the
-//     critical path leaves the register file).  The remembered pivot order of tf_cr2_hip.h stays:
+//     scalar operands -- no ds_bpermute, no DPP (nothing on the critical path leaves the register
+//     file).  The remembered pivot order of tf_cr2_hip.h stays:
 //     the rows are *loaded* in that order; growth above TF_GJ_GROWTH or anything non-finite sends the
 //     node to the search (tf_gj_wave, the old lane layout, on the rows in natural order);
 //   * the wavefront that eliminated node k has E = D^-1 L, F = D^-1 U, z = D^-1 y in registers and
