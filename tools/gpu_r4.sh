@@ -1,5 +1,5 @@
 #!/bin/bash
-# The GPU calls of round 4, one stage per call: gpurun -- bash tools/gpu_r4.sh <stage>   (stages: a b c d e f g h i)
+# The GPU calls of round 4, one stage per call: gpurun -- bash tools/gpu_r4.sh <stage>   (stages: a b c d e f g h i j)
 # Every stage writes under gpurun_out/; profiles/r04_ab_runs.txt and the other r04_* files quote them.
 case "$1" in
 a)
@@ -99,5 +99,11 @@ i)
     timeout -k 10 600 python3 tools/gpu_simulation_rate.py --iters 20 > $O/sim_cfg3.txt 2>&1; tail -4 $O/sim_cfg3.txt
     timeout -k 10 300 python3 tools/gpu_simulation_rate.py --config 2 --iters 20 > $O/sim_cfg2.txt 2>&1; tail -4 $O/sim_cfg2.txt
     ;;
-*) echo "usage: $0 <a|b|c|d|e|f|g|h|i>"; exit 2;;
+j)
+    # config 2 at N = 2e5: 19 800 steps/s in round 2, 9 800 in r4e -- which change?
+    bash tools/gpu_ab.sh r4j_cfg2_2e5 "--config 2 --nodes 200000" "" "|TRIFLOW_S_FUSE=0" "|TRIFLOW_M1=16" "|TRIFLOW_M1=4"
+    bash tools/gpu_trace_levels.sh r4j_trace --config 2 --nodes 200000 > /dev/null; cat gpurun_out/r4j_trace/levels.txt
+    bash tools/gpu_ab.sh r4j_cfg5 "--config 5" "" "|TRIFLOW_M1=48" "|TRIFLOW_M1=64"
+    ;;
+*) echo "usage: $0 <a|b|c|d|e|f|g|h|i|j>"; exit 2;;
 esac
