@@ -93,12 +93,7 @@ void launch(Module*, int kernel, unsigned gx, unsigned gy, unsigned block,
     case TFK_SWEEP_FJ: { const auto& a = *(const TfSweepArgs*)args;
         for (unsigned y = 0; y < gy; ++y) for (int64_t t = 0; t < nthreads; ++t) tfk_sweep_body<true>(a, (int)t, (int)y); } break;
     case TFK_SPMV: { const auto& a = *(const TfSpmvArgs*)args;
-        for (unsigned y = 0; y < gy; ++y) for (int64_t t = 0; t < nthreads; ++t) tfk_spmv_body<false>(a, (int)t, (int)y); } break;
-    case TFK_SPMV_MON: { const auto& a = *(const TfSpmvArgs*)args;
-        double m = *a.mon_red;
-        for (unsigned y = 0; y < gy; ++y) for (int64_t t = 0; t < nthreads; ++t) {
-            const double v = tfk_spmv_body<true>(a, (int)t, (int)y); m = (v > m || v != v) ? v : m; }
-        *a.mon_red = m; } break;
+        for (unsigned y = 0; y < gy; ++y) for (int64_t t = 0; t < nthreads; ++t) tfk_spmv_body(a, (int)t, (int)y); } break;
     case TFK_VEC: { const auto& a = *(const TfVecArgs*)args;
         for (int64_t i = 0; i < a.n; ++i) tfk_vec_elem(a, i); } break;
     case TFK_VEC_MAXABS: { const auto& a = *(const TfVecArgs*)args;

@@ -1198,7 +1198,7 @@ def check_fused_stage_rhs(backend):
                 ens = Ensemble(m, fd["x"], fields, pars, bool(pars["periodic"]), scheme=sch, hook=hook, nstate=2)
             finally:
                 del os.environ["TRIFLOW_FUSE_STAGE"]
-            for k in range(12):                      # long enough to include a monitored step (n_factor = 4)
+            for k in range(6):
                 ens.step(dt)
             ens.sync()
             out.append(ens.state().copy())
@@ -1207,9 +1207,9 @@ def check_fused_stage_rhs(backend):
 
 
 def check_row_monitor(backend):
-    """Every Rosenbrock step measures the backward error of its factorisation inside the J @ v
-    pass of stage 1 (quotients are only formed above 1e-12).  (i) A healthy factorisation reads 0,
-    like the explicit check of the same solve reads rounding level.  (ii) A factorisation that
+    """Every Rosenbrock step measures the backward error of its stage-0 solve at one node per chunk
+    (tf_solver::monitor_sampled, a launch nobody waits for).  (i) A healthy factorisation reads rounding
+    level, like the explicit check of the same solve.  (ii) A factorisation that
     loses accuracy while no explicit check runs -- a dispersive model on 4-node chunks, checks
     switched off -- is reported by the next synchronising call instead of passing silently."""
     from triflow_amd.ensemble import Ensemble
@@ -1220,7 +1220,7 @@ def check_row_monitor(backend):
     ens.step(dt)
     mon = ens.solver.monitor_error()
     chk, _ = ens.solver.backward_error()
-    assert mon == 0.0 and 0 < chk < 1e-12, (mon, chk)
+    assert 0 <= mon < 1e-12 and 0 < chk < 1e-12, (mon, chk)
     ens.sync()                                                  # resets the monitor
     assert ens.solver.monitor_error() == 0.0
     ens.close()

@@ -581,6 +581,44 @@ def test_state_update_inside_the_back_substitution(cfg, sch, N, nsys, m1, monkey
     assert vec_launches[1] == 5 and vec_launches[0] == (5 if sch == "RODASPR" else 0), vec_launches
 
 
+@pytest.mark.parametrize("cfg,sch,N,nsys,m1", [(3, "ROS2", 70003, 1, 32), (3, "RODASPR", 40009, 2, 13),
+                                                 (5, "BDF2", 50021, 1, 16), (5, "Theta", 33013, 3, 11),
+                                                 (3, "ROS2", 9001, 1, 4)])
+def test_level_two_inside_the_level_one_launches(cfg, sch, N, nsys, m1, monkeypatch):
+    """3 <= b <= 6 and a plan of four or more levels: tfk_l1_solve_cr / tfk_l1_fwd2_backsub_cr run level 2's
+    cyclic reduction in the workgroups that walk the level-1 chunks around its nodes -- the bodies of
+    tfk_l1_solve + tfk_cr_fwd and of tfk_cr_bwd + tfk_l1_fwd2_backsub, the same bits -- with one and several
+    members, periodic and clamped with a hook, level-2 chunk counts that are no multiple of four."""
+    from triflow_amd.ensemble import Ensemble
+    name, fd, pars, dt, _ = corpus.config_inputs(cfg, N)
+    m = pc.device_model(name, HIP)
+    fields = {k: np.repeat(v[None, :], nsys, axis=0) * (1 + 0.01 * np.arange(nsys))[:, None]
+              for k, v in fd.items() if k != "x"}
+    hook = pc.DEVICE_HOOKS["cfg5"] if cfg == 5 else None
+    monkeypatch.setenv("TRIFLOW_L1_RESPIKE", "1")
+    out, reps = [], []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("TRIFLOW_L1CR_FUSE", fuse)
+        ens = Ensemble(m, fd["x"], fields, pars, bool(pars["periodic"]), scheme=sch, hook=hook, nstate=2, m1=m1, refine=0)
+        assert len(ens.solver.describe()["chunks"]) >= 4, ens.solver.describe()
+        ens.solver.timing(True)
+        for _ in range(4):
+            ens.step(dt)
+        ens.sync()
+        out.append(ens.state().copy())
+        reps.append(ens.solver.timing_report())
+        ens.close()
+    assert np.isfinite(out[0]).all() and np.array_equal(out[0], out[1])
+    assert "tfk_l1_fwd2_backsub_cr" in reps[0] and "tfk_l1_fwd2_backsub" not in reps[0], sorted(reps[0])
+    assert "tfk_l1_fwd2_backsub_cr" not in reps[1] and "tfk_l1_fwd2_backsub" in reps[1], sorted(reps[1])
+    assert reps[0]["tfk_cr_bwd"][1] < reps[1]["tfk_cr_bwd"][1]       # (one level fewer in the reduced-level launches)
+    if "tfk_l1_solve" in reps[1]:                  # (a step with a solve that does not ride with the factorisation)
+        assert "tfk_l1_solve_cr" in reps[0] and "tfk_l1_solve" not in reps[0], sorted(reps[0])
+        assert "tfk_l1_solve_cr" not in reps[1] and reps[0].get("tfk_cr_fwd", (0, 0))[1] < reps[1]["tfk_cr_fwd"][1]
+    else:
+        assert sch in ("BDF2", "Theta")
+
+
 def test_fused_stage_rhs():
     pc.check_fused_stage_rhs(HIP)
 

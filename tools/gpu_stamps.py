@@ -53,5 +53,12 @@ for l in range(1, len(s.describe()["chunks"])):
               % (r[44] - marks[3], r[45] - r[44], r[46] - r[45], r[47] - r[46], r[48] - r[47], marks[5] - r[48]))
     if r[50]:
         print("         tail kernel (this level + the last one): " + " ".join(str(int(v)) for v in np.diff(r[50:57])) + " cycles (requests, forward, park, last level, barrier, backward)")
+    if r[57] and r[61]:
+        print("         level 1 + this level forwards in one launch (tfk_l1_solve_cr, wavefront 0): walks %d | barrier %d | first chunk %d | second chunk %d cycles"
+              % (r[58] - r[57], r[59] - r[58], r[60] - r[59], r[61] - r[60]))
+        if r[42]:
+            print("             first chunk: records in LDS after %d | rounds %d | end %d" % (r[42] - r[59], r[43] - r[42], r[60] - r[43]))
+    if r[62] and r[63]:
+        print("         this level + level 1 backwards in one launch (tfk_l1_fwd2_backsub_cr, wavefront 0): its two chunks %d cycles" % (r[63] - r[62]))
     if r[41]:
         print("         block inversions %d, of which with the pivot search %d (all steps so far)" % (r[41], r[40]))

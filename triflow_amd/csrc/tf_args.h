@@ -82,12 +82,6 @@ struct TfSpmvArgs {                // y = scale * J @ v  (clamped/wrapped column
     double vc[TF_MAX_TERMS];
     const double* addF;
     double cF, cA;
-    // Monitor of the previous solve (Rosenbrock stage 1: v = g * k0 with k0 the solution of
-    // (I - cJ) k0 = mon_rhs): its componentwise backward error  |b - x + cJx| / (|x| + |cJ||x| + |b|)
-    // falls out of this pass over J; the maximum goes to *mon_red (atomic max of the bit pattern).
-    const double* mon_rhs;          // NULL: off
-    double mon_c, mon_inv_g;
-    double* mon_red;
 };
 
 struct TfNormArgs {               // per-variable, per-system norm of (a - b): partial sums
@@ -333,9 +327,9 @@ enum TfKernel {
     TFK_L1_FACTOR, TFK_L1_SOLVE, TFK_L1_ASM_MAT, TFK_L1_ASM_RHS, TFK_L1_BACKSUB,
     TFK_BT_LU, TFK_BT_SPIKE, TFK_BT_RHS, TFK_BT_ASM_MAT, TFK_BT_ASM_RHS, TFK_BT_BACKSUB,
     TFK_TOP_FACTOR, TFK_TOP_SOLVE, TFK_BERR, TFK_DIFFNORM, TFK_L1_FACTOR_RHS, TFK_SWEEP_F_STAGE,
-    TFK_CR_FACTOR, TFK_CR_FWD, TFK_CR_BWD, TFK_POKE, TFK_SWEEP_FJ_THETA, TFK_SWEEP_FJ_BDF2, TFK_SPMV_MON, TFK_GATHER,
+    TFK_CR_FACTOR, TFK_CR_FWD, TFK_CR_BWD, TFK_POKE, TFK_SWEEP_FJ_THETA, TFK_SWEEP_FJ_BDF2, TFK_GATHER,
     TFK_SWEEP_F_STAGE_RHS, TFK_L1_FWD2, TFK_L1_BACKSUB_U, TFK_CR_TAIL, TFK_L1_FWD2_BACKSUB, TFK_TINY_FACTOR, TFK_TINY_SOLVE,
-    TFK_S_FWD, TFK_S_BWD, TFK_SWEEP_F_STAGE_RHS_N, TFK_COUNT
+    TFK_S_FWD, TFK_S_BWD, TFK_SWEEP_F_STAGE_RHS_N, TFK_L1_SOLVE_CR, TFK_L1_FWD2_BACKSUB_CR, TFK_COUNT
 };
 #define TF_KERNEL_NAMES { \
     "tfk_sweep_f", "tfk_sweep_fj", "tfk_spmv", "tfk_vec", "tfk_vec_maxabs", "tfk_perm", "tfk_dirichlet", \
@@ -343,5 +337,6 @@ enum TfKernel {
     "tfk_bt_lu", "tfk_bt_spike", "tfk_bt_rhs", "tfk_bt_asm_mat", "tfk_bt_asm_rhs", "tfk_bt_backsub", \
     "tfk_top_factor", "tfk_top_solve", "tfk_berr", "tfk_diffnorm", "tfk_l1_factor_rhs", "tfk_sweep_f_stage", \
     "tfk_cr_factor", "tfk_cr_fwd", "tfk_cr_bwd", "tfk_poke", "tfk_sweep_fj_theta", "tfk_sweep_fj_bdf2", \
-    "tfk_spmv_mon", "tfk_gather", "tfk_sweep_f_stage_rhs", "tfk_l1_fwd2", "tfk_l1_backsub_u", "tfk_cr_tail", \
-    "tfk_l1_fwd2_backsub", "tfk_tiny_factor", "tfk_tiny_solve", "tfk_s_fwd", "tfk_s_bwd", "tfk_sweep_f_stage_rhs_n" }
+    "tfk_gather", "tfk_sweep_f_stage_rhs", "tfk_l1_fwd2", "tfk_l1_backsub_u", "tfk_cr_tail", \
+    "tfk_l1_fwd2_backsub", "tfk_tiny_factor", "tfk_tiny_solve", "tfk_s_fwd", "tfk_s_bwd", "tfk_sweep_f_stage_rhs_n", \
+    "tfk_l1_solve_cr", "tfk_l1_fwd2_backsub_cr" }

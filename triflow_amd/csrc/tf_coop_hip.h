@@ -547,27 +547,14 @@ template <int BB> struct TfCrIo {
     }
 };
 
-// forward elimination of the right-hand side through chunk `ch`; tid = lane of its wavefront.
-// zkeep[r] (optional): z of this lane's task of round r stays in a register for the
-// back-substitution of the same launch.
-template <int BB, bool KEEPZ = false>
-__device__ __forceinline__ void tfk_cr_fwd_chunk(const TfLevelArgs& a, const TfCrChunk<BB>& ch, int tid,
-                                                 TfCrSolveLds<BB>& sh, const TfCrIo<BB>& io,
-                                                 double* zkeep = nullptr) {
-    typedef TfCr<BB> C;
-    constexpr int G = C::G, B2 = BB * BB, MAXR = 4;
-    static_assert(C::MAXLEN <= 16, "round count");
-    const TfLayout& L = a.L;
+// The rows of the stored reduction a lane's forward tasks need (independent of the right-hand side)
+template <int BB> struct TfCrFwdRows { double Di[4][BB], Lb[4][BB], Ua[4][BB]; };
+template <int BB>
+__device__ __forceinline__ void tfk_cr_fwd_load(const TfCrChunk<BB>& ch, int tid, const TfCrIo<BB>& io, TfCrFwdRows<BB>& rows) {
+    constexpr int G = TfCr<BB>::G, B2 = BB * BB, MAXR = 4;
     const int grp = tid / G, g = tid % G;
     const bool row_on = g < BB;
-    const int mI = ch.mI, pe = ch.pe, len = ch.len;
-    double (&sY)[TfCrSolveLds<BB>::NPOS][BB] = sh.sY;
-    double (&sZ)[TfCrSolveLds<BB>::NPOS][BB] = sh.sZ;
-    double* sYr = sh.sYr;
-
-    tf_wave_sync();                                  // (the block may still be read by the previous chunk's phases)
-    for (int i = tid; i < len * 2 * BB; i += 64) sYr[2 * BB + i] = io.ys[i];
-    double Di[MAXR][BB], Lb[MAXR][BB], Ua[MAXR][BB];
+    const int mI = ch.mI;
 #pragma unroll
     for (int r = 0; r < MAXR; ++r) {
         const int s = 1 << r;
@@ -582,11 +569,55 @@ __device__ __forceinline__ void tfk_cr_fwd_chunk(const TfLevelArgs& a, const TfC
         const double* rk = io.crf0 + ((onA ? k : 1) - 1) * 5 * B2 + g * BB;
         const double* rl = io.crf0 + ((vL ? kL : 1) - 1) * 5 * B2 + 4 * B2 + g * BB;
         const double* rr = io.crf0 + ((vR ? kR : 1) - 1) * 5 * B2 + 3 * B2 + g * BB;
-        tf_load_row<BB>(rk, onA, Di[r]);
-        tf_load_row<BB>(rl, vL, Lb[r]);
-        tf_load_row<BB>(rr, vR, Ua[r]);
+        tf_load_row<BB>(rk, onA, rows.Di[r]);
+        tf_load_row<BB>(rl, vL, rows.Lb[r]);
+        tf_load_row<BB>(rr, vR, rows.Ua[r]);
     }
+}
+// ... and the chunk's right-hand side records, TF_CR_NYS(b) values per lane
+#define TF_CR_NYS(b) ((TF_CR_MAXLEN * 2 * (b) + 63) / 64)
+template <int BB>
+__device__ __forceinline__ void tfk_cr_fwd_load_ys(const TfCrChunk<BB>& ch, int tid, const TfCrIo<BB>& io, double (&ysv)[TF_CR_NYS(BB)]) {
+#pragma unroll
+    for (int q = 0; q < TF_CR_NYS(BB); ++q) ysv[q] = tid + 64 * q < ch.len * 2 * BB ? io.ys[tid + 64 * q] : 0.0;
+}
+
+// forward elimination of the right-hand side through chunk `ch`; tid = lane of its wavefront.
+// zkeep[r] (optional): z of this lane's task of round r stays in a register for the
+// back-substitution of the same launch.  pre / ysv (optional): rows and right-hand side records
+// requested by the caller earlier (tfk_cr_fwd_load, tfk_cr_fwd_load_ys).
+template <int BB, bool KEEPZ = false, bool PRE = false>
+__device__ __forceinline__ void tfk_cr_fwd_chunk(const TfLevelArgs& a, const TfCrChunk<BB>& ch, int tid,
+                                                 TfCrSolveLds<BB>& sh, const TfCrIo<BB>& io,
+                                                 double* zkeep = nullptr, const TfCrFwdRows<BB>* pre = nullptr,
+                                                 const double* ysv = nullptr) {
+    typedef TfCr<BB> C;
+    constexpr int G = C::G, B2 = BB * BB, MAXR = 4;
+    static_assert(C::MAXLEN <= 16, "round count");
+    const TfLayout& L = a.L;
+    const int grp = tid / G, g = tid % G;
+    const bool row_on = g < BB;
+    const int mI = ch.mI, pe = ch.pe, len = ch.len;
+    double (&sY)[TfCrSolveLds<BB>::NPOS][BB] = sh.sY;
+    double (&sZ)[TfCrSolveLds<BB>::NPOS][BB] = sh.sZ;
+    double* sYr = sh.sYr;
+
+    tf_wave_sync();                                  // (the block may still be read by the previous chunk's phases)
+    TfCrFwdRows<BB> own;
+    if constexpr (PRE) {
+#pragma unroll
+        for (int q = 0; q < TF_CR_NYS(BB); ++q)
+            if (tid + 64 * q < len * 2 * BB) sYr[2 * BB + tid + 64 * q] = ysv[q];
+    } else {
+        for (int i = tid; i < len * 2 * BB; i += 64) sYr[2 * BB + i] = io.ys[i];
+        tfk_cr_fwd_load<BB>(ch, tid, io, own);
+    }
+    const TfCrFwdRows<BB>& rw = PRE ? *pre : own;
+    const double (&Di)[4][BB] = rw.Di;
+    const double (&Lb)[4][BB] = rw.Lb;
+    const double (&Ua)[4][BB] = rw.Ua;
     tf_wave_sync();
+    if (PRE && (ch.p & 3) == 0) TF_STAMP(a, 42);
     for (int i = tid; i < (len + 1) * BB; i += 64) {
         const int pos = i / BB, r = i - pos * BB;
         sY[pos][r] = pos > 0 ? sYr[pos * 2 * BB + r] + sYr[pos * 2 * BB + BB + r] : 0.0;
@@ -626,6 +657,7 @@ __device__ __forceinline__ void tfk_cr_fwd_chunk(const TfLevelArgs& a, const TfC
             tf_wave_sync();
         }
     }
+    if (PRE && (ch.p & 3) == 0) TF_STAMP(a, 43);
     if (a.fold_top) {
         // last level: apply the inverse of the remaining block (tfk_cr_factor_v3) and run
         // the back-substitution rounds of this level right away (tfk_cr_bwd_run)
@@ -699,10 +731,19 @@ __device__ __forceinline__ void tfk_cr_bwd_load(const TfLevelArgs& a, const TfCr
 
 // ef (optional): the E and F blocks of the chunk's nodes staged in LDS, [node][2][b][b] from the
 // chunk's first node -- then rows.Er / rows.Fr are not used (only rows.zk)
-template <int BB, bool USE_EF = false>
+// PREX: xsep = the caller's earlier load of tfk_cr_bwd_sep (the separators that bound the chunk)
+template <int BB>
+__device__ __forceinline__ double tfk_cr_bwd_sep(int tid, const TfCrIo<BB>& io) {
+    constexpr int G = TfCr<BB>::G;
+    const int grp = tid / G, g = tid % G;
+    if (g < BB && grp == 0) return io.xn_own[g];
+    if (g < BB && grp == 1 && io.has_xprev) return io.xn_prev[g];
+    return 0.0;
+}
+template <int BB, bool USE_EF = false, bool PREX = false>
 __device__ __forceinline__ void tfk_cr_bwd_run(const TfLevelArgs& a, const TfCrChunk<BB>& ch, int tid,
                                                TfCrSolveLds<BB>& sh, const TfCrIo<BB>& io,
-                                               const TfCrBwdRows<BB>& rows, const double* ef = nullptr) {
+                                               const TfCrBwdRows<BB>& rows, const double* ef = nullptr, double xsep = 0.0) {
     constexpr int G = TfCr<BB>::G, MAXR = 4, B2 = BB * BB;
     const int grp = tid / G, g = tid % G;
     const bool row_on = g < BB;
@@ -710,11 +751,11 @@ __device__ __forceinline__ void tfk_cr_bwd_run(const TfLevelArgs& a, const TfCrC
     double (&sX)[TfCrSolveLds<BB>::NPOS][BB] = sh.sY;
     tf_wave_sync();
     if (row_on && grp == 0) {
-        const double xs = io.xn_own[g];
+        const double xs = PREX ? xsep : io.xn_own[g];
         sX[pe][g] = xs;
         a.x[(ch.nbase + ch.node(pe)) * BB + g] = xs;
     }
-    if (row_on && grp == 1) sX[0][g] = io.has_xprev ? io.xn_prev[g] : 0.0;
+    if (row_on && grp == 1) sX[0][g] = PREX ? xsep : (io.has_xprev ? io.xn_prev[g] : 0.0);
     tf_wave_sync();
 #pragma unroll
     for (int r = MAXR - 1; r >= 0; --r) {

@@ -17,7 +17,12 @@
 // launch (tfk_s_fwd) without writing back / invalidating whole caches
 #define TF_ST_AGENT(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define TF_LD_AGENT(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+// between two phases that one wavefront runs alone: LDS executes a wavefront's instructions in order,
+// the compiler only has to keep them in order
+#define TF_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #else
+#define TF_WAVE_SYNC() do {} while (0)
 #define TF_ST_AGENT(p, v) (*(p) = (v))
 #define TF_LD_AGENT(p) (*(p))
 #define TF_LDS static thread_local
@@ -52,6 +57,12 @@ struct TfCrChunk {
 // chunks, where the chunk walks needed 6 levels of three kernels each).
 template <int BB> struct TfCrs {
     static constexpr int MAXLEN = TF_CRS_MAXLEN, NPOS = MAXLEN + 1;
+    // LDS places of the solve kernels (tfk_crs_fwd / tfk_crs_bwd): a vector [pos][b], records [pos][5][b][b].
+    // (Padding them against the bank conflicts of the power-of-two strides of the rounds changed nothing:
+    // a round is bound by the instructions one wavefront issues, profiles/r04_scalar_stamps.txt.)
+    static constexpr int VSIZE = NPOS * BB, FSIZE = NPOS * 5 * BB * BB;
+    TF_DEVICE_M static int v(int pos, int q) { return pos * BB + q; }
+    TF_DEVICE_M static int f(int pos) { return pos * 5 * BB * BB; }
 };
 
 // small-block helpers on rows stored as [r * BB + c] in LDS / global memory
@@ -240,74 +251,127 @@ template <int BB, int NT>
 TF_DEVICE void tfk_crs_stage(const TfLevelArgs& a, int chunk, int tid, double* sF) {
     const TfCrChunk<BB> ch(a.L, chunk);
     const double* src = a.crf + (ch.nbase + ch.start) * 5 * BB * BB;
-    for (int i = tid; i < ch.len * 5 * BB * BB; i += NT) sF[5 * BB * BB + i] = src[i];
+    for (int i = tid; i < ch.len * 5 * BB * BB; i += NT) {
+        const int nd = i / (5 * BB * BB);
+        sF[TfCrs<BB>::f(nd + 1) + i - nd * 5 * BB * BB] = src[i];
+    }
+}
+// ... in two parts, for a caller with work to do while the loads are in flight: request (into registers),
+// then put into LDS
+template <int BB, int NT> struct TfCrsStaged { double v[(TF_CRS_MAXLEN * 5 * BB * BB + NT - 1) / NT]; };
+template <int BB, int NT>
+TF_DEVICE void tfk_crs_stage_request(const TfLevelArgs& a, int chunk, int tid, TfCrsStaged<BB, NT>& regs) {
+    const TfCrChunk<BB> ch(a.L, chunk);
+    const double* src = a.crf + (ch.nbase + ch.start) * 5 * BB * BB;
+    constexpr int NQ = (TF_CRS_MAXLEN * 5 * BB * BB + NT - 1) / NT;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) regs.v[q] = tid + q * NT < ch.len * 5 * BB * BB ? src[tid + q * NT] : 0.0;
+}
+template <int BB, int NT>
+TF_DEVICE void tfk_crs_stage_put(const TfLevelArgs& a, int chunk, int tid, const TfCrsStaged<BB, NT>& regs, double* sF) {
+    const TfCrChunk<BB> ch(a.L, chunk);
+    constexpr int NQ = (TF_CRS_MAXLEN * 5 * BB * BB + NT - 1) / NT;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int i = tid + q * NT, nd = i / (5 * BB * BB);
+        if (i < ch.len * 5 * BB * BB) sF[TfCrs<BB>::f(nd + 1) + i - nd * 5 * BB * BB] = regs.v[q];
+    }
 }
 
 // STAGED: the caller has put the stored reduction into `sF` already (tfk_crs_stage: a kernel that
 // walks level 1 first requests it before the walks, tfk_s_fwd)
 // AGENT_OUT / AGENT_IN: this chunk's share of the next level's right-hand side is stored / this level's
 // right-hand side is loaded with agent-scope accesses (a producer / the consumer inside one launch)
-template <int BB, int NT, bool STAGED = false, bool AGENT_OUT = false, bool AGENT_IN = false>
-TF_DEVICE void tfk_crs_fwd(const TfLevelArgs& a, int chunk, int tid, double* sF_staged = nullptr) {
+// ys_own: the chunk's right-hand side records [len][2][b] where the caller's walks left them (LDS) instead
+// of a.rhs; top_pre: the caller's earlier load of this lane's entry of the folded top block's inverse
+// (thread 0 .. b*b-1: entry tid; with fold_top)
+template <int BB, int NT, bool STAGED = false, bool AGENT_OUT = false, bool AGENT_IN = false, bool PRE = false>
+TF_DEVICE void tfk_crs_fwd(const TfLevelArgs& a, int chunk, int tid, double* sF_staged = nullptr,
+                           const double* ys_own = nullptr, const double* top_pre = nullptr) {
     typedef TfCrs<BB> C;
     constexpr int NPOS = C::NPOS, B2 = BB * BB;
     const TfLayout& L = a.L;
     const TfCrChunk<BB> ch(L, chunk);
     const int mI = ch.mI, pe = ch.pe, len = ch.len;
-    TF_LDS double sF_own[STAGED ? 1 : NPOS * 5 * B2];             // stored reduction of the chunk's nodes
-    TF_LDS double sY[NPOS * BB], sZ[NPOS * BB];
+    TF_LDS double sF_own[STAGED ? 1 : C::FSIZE];             // stored reduction of the chunk's nodes
+    TF_LDS double sY[C::VSIZE], sZ[C::VSIZE];
     double* const sF = STAGED ? sF_staged : sF_own;
     {
         if (!STAGED) tfk_crs_stage<BB, NT>(a, chunk, tid, sF);
-        const double* ys = a.rhs + (ch.nbase + ch.start) * 2 * BB;
+        const double* ys = ys_own ? ys_own : a.rhs + (ch.nbase + ch.start) * 2 * BB;
         for (int i = tid; i < (len + 1) * BB; i += NT) {
             const int pos = i / BB, r = i - pos * BB;
-            if (AGENT_IN) sY[i] = pos > 0 ? TF_LD_AGENT(ys + (pos - 1) * 2 * BB + r) + TF_LD_AGENT(ys + (pos - 1) * 2 * BB + BB + r) : 0.0;
-            else sY[i] = pos > 0 ? ys[(pos - 1) * 2 * BB + r] + ys[(pos - 1) * 2 * BB + BB + r] : 0.0;
+            if (AGENT_IN) sY[C::v(pos, r)] = pos > 0 ? TF_LD_AGENT(ys + (pos - 1) * 2 * BB + r) + TF_LD_AGENT(ys + (pos - 1) * 2 * BB + BB + r) : 0.0;
+            else sY[C::v(pos, r)] = pos > 0 ? ys[(pos - 1) * 2 * BB + r] + ys[(pos - 1) * 2 * BB + BB + r] : 0.0;
         }
     }
     TF_BARRIER();
-    for (int s = 1; s <= mI; s <<= 1) {
-        const int nA = (mI / s + 1) / 2;
+    // One phase per round: the lane that updates node aa's right-hand side in round r is the one that goes
+    // on to z_aa = Dinv_aa y_aa when aa leaves in round r + 1 (every second one does), so that the update
+    // and the next round's first half need one set of LDS loads and one synchronisation -- a wavefront
+    // alone on its SIMD issues an instruction every ~5 cycles and waits ~130 for LDS: a round of two
+    // phases took 1150 cycles (profiles/r04_scalar_stamps.txt).
+    // Phases with at most 64 tasks (all but the first two of a 256-node chunk) are run by the first
+    // wavefront ALONE, with no workgroup barrier in between.  `alone`: the other wavefronts have not been
+    // synchronised with what the first one wrote since; a barrier is due before they take part again,
+    // and at the end.
+    constexpr int WS = NT > 64 ? 64 : NT;
+    bool alone = false;
+    if (mI >= 1) {
+        const int nA = (mI + 1) >> 1;                        // round 0's first half: the odd nodes
         for (int j = tid; j < nA; j += NT) {
-            const int k = s * (2 * j + 1);
+            const int k = 2 * j + 1;
             double Di[BB][BB], y[BB], z[BB];
-            tf_ld_blk<BB>(Di, sF + k * 5 * B2);
+            tf_ld_blk<BB>(Di, sF + C::f(k));
 #pragma unroll
-            for (int r = 0; r < BB; ++r) y[r] = sY[k * BB + r];
+            for (int q = 0; q < BB; ++q) y[q] = sY[C::v(k, q)];
             tf_mv<BB>(z, Di, y);
 #pragma unroll
-            for (int r = 0; r < BB; ++r) { sZ[k * BB + r] = z[r]; a.zt[(ch.nbase + ch.node(k)) * BB + r] = z[r]; }
+            for (int q = 0; q < BB; ++q) { sZ[C::v(k, q)] = z[q]; a.zt[(ch.nbase + ch.node(k)) * BB + q] = z[q]; }
         }
         TF_BARRIER();
-        const int nB = mI / (2 * s);
-        for (int t = tid; t <= nB; t += NT) {
-            const bool ends = t == nB;
-            const int aa = 2 * s * (t + 1), nq = mI / s;
-            const int aL = ends ? pe : aa, aU = ends ? 0 : aa;
-            const bool vL = ends ? (nq & 1) != 0 : true;
-            const bool vR = ends ? true : aa + s <= mI;
-            const int kL = ends ? nq * s : aa - s, kR = ends ? s : aa + s;
-            if (vL) {
-                double Lb[BB][BB], zk[BB], yv[BB];
-                tf_ld_blk<BB>(Lb, sF + kL * 5 * B2 + 4 * B2);
+    }
+    for (int r = 0; (1 << r) <= mI; ++r) {
+        const int s = 1 << r, nq = mI >> r, nB = nq >> 1;
+        const int nA1 = (2 << r) <= mI ? ((mI >> (r + 1)) + 1) >> 1 : 0;      // nodes that leave in round r + 1
+        const bool solo = NT > 64 && nB + 1 <= 64;
+        if (!solo && alone) { TF_BARRIER(); alone = false; }
+        const int st = solo ? WS : NT;
+        if (!solo || tid < WS)
+            for (int t = tid; t <= nB; t += st) {
+                const bool ends = t == nB;
+                const int aa = 2 * s * (t + 1);
+                const int aL = ends ? pe : aa, aU = ends ? 0 : aa;
+                const bool vL = ends ? (nq & 1) != 0 : true;
+                const bool vR = ends ? true : aa + s <= mI;
+                const int kL = vL ? (ends ? nq * s : aa - s) : 1, kR = vR ? (ends ? s : aa + s) : 1;
+                const bool next = !ends && (t & 1) == 0 && (t >> 1) < nA1;    // aa = 2 s (2 j' + 1), j' = t / 2
+                // (every load of the task before the first use)
+                double Lb[BB][BB], Ua[BB][BB], Di[BB][BB], zl[BB], zr[BB], yl[BB], yu[BB];
+                tf_ld_blk<BB>(Lb, sF + C::f(kL) + 4 * B2);
+                tf_ld_blk<BB>(Ua, sF + C::f(kR) + 3 * B2);
+                tf_ld_blk<BB>(Di, sF + C::f(next ? aa : 1));
 #pragma unroll
-                for (int r = 0; r < BB; ++r) { zk[r] = sZ[kL * BB + r]; yv[r] = sY[aL * BB + r]; }
-                tf_mv_sub<BB>(yv, Lb, zk);
+                for (int q = 0; q < BB; ++q) { zl[q] = sZ[C::v(kL, q)]; zr[q] = sZ[C::v(kR, q)]; yl[q] = sY[C::v(aL, q)]; yu[q] = sY[C::v(aU, q)]; }
+                if (vL) tf_mv_sub<BB>(yl, Lb, zl);
+                if (!ends) {
+                    // (one node takes both updates, the lower neighbour's first)
+                    if (vR) tf_mv_sub<BB>(yl, Ua, zr);
 #pragma unroll
-                for (int r = 0; r < BB; ++r) sY[aL * BB + r] = yv[r];
+                    for (int q = 0; q < BB; ++q) sY[C::v(aL, q)] = yl[q];
+                    if (next) {
+                        double z[BB];
+                        tf_mv<BB>(z, Di, yl);
+#pragma unroll
+                        for (int q = 0; q < BB; ++q) { sZ[C::v(aa, q)] = z[q]; a.zt[(ch.nbase + ch.node(aa)) * BB + q] = z[q]; }
+                    }
+                } else {
+                    if (vR) tf_mv_sub<BB>(yu, Ua, zr);
+#pragma unroll
+                    for (int q = 0; q < BB; ++q) { if (vL) sY[C::v(aL, q)] = yl[q]; if (vR) sY[C::v(aU, q)] = yu[q]; }
+                }
             }
-            if (vR) {
-                double Ua[BB][BB], zk[BB], yv[BB];
-                tf_ld_blk<BB>(Ua, sF + kR * 5 * B2 + 3 * B2);
-#pragma unroll
-                for (int r = 0; r < BB; ++r) { zk[r] = sZ[kR * BB + r]; yv[r] = sY[aU * BB + r]; }
-                tf_mv_sub<BB>(yv, Ua, zk);
-#pragma unroll
-                for (int r = 0; r < BB; ++r) sY[aU * BB + r] = yv[r];
-            }
-        }
-        TF_BARRIER();
+        if (solo) { TF_WAVE_SYNC(); alone = true; } else TF_BARRIER();
     }
     if (a.fold_top) {
         if (tid == 0) {
@@ -315,48 +379,54 @@ TF_DEVICE void tfk_crs_fwd(const TfLevelArgs& a, int chunk, int tid, double* sF_
             double Si[BB][BB], yt[BB], x[BB];
 #pragma unroll
             for (int r = 0; r < BB; ++r) {
-                yt[r] = sY[pe * BB + r] + sY[r];
+                yt[r] = sY[C::v(pe, r)] + sY[C::v(0, r)];
 #pragma unroll
-                for (int c = 0; c < BB; ++c) Si[r][c] = a.topAinv[(int64_t)(r * BB + c) * nsys + ch.e];
+                for (int c = 0; c < BB; ++c) Si[r][c] = PRE ? top_pre[r * BB + c] : a.topAinv[(int64_t)(r * BB + c) * nsys + ch.e];
             }
             tf_mv<BB>(x, Si, yt);
 #pragma unroll
             for (int r = 0; r < BB; ++r) {
                 a.topx[(int64_t)ch.e * BB + r] = x[r];
                 a.x[(ch.nbase + ch.node(pe)) * BB + r] = x[r];
-                sY[pe * BB + r] = x[r];
-                sY[r] = ch.has_prev ? x[r] : 0.0;
+                sY[C::v(pe, r)] = x[r];
+                sY[C::v(0, r)] = ch.has_prev ? x[r] : 0.0;
             }
         }
-        TF_BARRIER();
-        int s = 1;
-        while (2 * s <= mI) s <<= 1;
-        for (; s >= 1; s >>= 1) {
-            const int nA = (mI / s + 1) / 2;
-            for (int j = tid; j < nA; j += NT) {
-                const int k = s * (2 * j + 1);
-                const int kl = k - s, kr = k + s <= mI ? k + s : pe;
-                double E[BB][BB], F[BB][BB], xl[BB], xr[BB], xk[BB];
-                tf_ld_blk<BB>(E, sF + k * 5 * B2 + B2); tf_ld_blk<BB>(F, sF + k * 5 * B2 + 2 * B2);
+        if (alone) TF_WAVE_SYNC(); else TF_BARRIER();
+        int r = 0;
+        while ((2 << r) <= mI) ++r;
+        for (; r >= 0; --r) {
+            const int s = 1 << r, nA = ((mI >> r) + 1) >> 1;
+            const bool solo = NT > 64 && nA <= 64;
+            if (!solo && alone) { TF_BARRIER(); alone = false; }
+            const int st = solo ? WS : NT;
+            if (!solo || tid < WS)
+                for (int j = tid; j < nA; j += st) {
+                    const int k = s * (2 * j + 1);
+                    const int kl = k - s, kr = k + s <= mI ? k + s : pe;
+                    double E[BB][BB], F[BB][BB], xl[BB], xr[BB], xk[BB];
+                    tf_ld_blk<BB>(E, sF + C::f(k) + B2); tf_ld_blk<BB>(F, sF + C::f(k) + 2 * B2);
 #pragma unroll
-                for (int r = 0; r < BB; ++r) { xk[r] = sZ[k * BB + r]; xl[r] = sY[kl * BB + r]; xr[r] = sY[kr * BB + r]; }
-                tf_mv_sub<BB>(xk, E, xl); tf_mv_sub<BB>(xk, F, xr);
+                    for (int q = 0; q < BB; ++q) { xk[q] = sZ[C::v(k, q)]; xl[q] = sY[C::v(kl, q)]; xr[q] = sY[C::v(kr, q)]; }
+                    tf_mv_sub<BB>(xk, E, xl); tf_mv_sub<BB>(xk, F, xr);
 #pragma unroll
-                for (int r = 0; r < BB; ++r) { sY[k * BB + r] = xk[r]; a.x[(ch.nbase + ch.node(k)) * BB + r] = xk[r]; }
-            }
-            TF_BARRIER();
+                    for (int q = 0; q < BB; ++q) { sY[C::v(k, q)] = xk[q]; a.x[(ch.nbase + ch.node(k)) * BB + q] = xk[q]; }
+                }
+            if (solo) { TF_WAVE_SYNC(); alone = true; } else TF_BARRIER();
         }
     } else {
+        // (the first wavefront's threads: what they read was written by it, or before a barrier)
         for (int side = tid; side < 2; side += NT) {
             const int nn = side == 0 ? ch.p : ch.pprev;
             double* rr = a.rhsnext + ((int64_t)ch.e * a.Lnext.N + nn) * 2 * BB;
             for (int r = 0; r < BB; ++r) {
                 double* dst = side == 0 ? rr + r : rr + BB + r;
-                const double v = side == 0 ? sY[pe * BB + r] : sY[r];
+                const double v = side == 0 ? sY[C::v(pe, r)] : sY[C::v(0, r)];
                 if (AGENT_OUT) TF_ST_AGENT(dst, v); else *dst = v;
             }
         }
     }
+    if (alone) TF_BARRIER();
 }
 
 // store_prev: the solution of the separator above (a node of the previous chunk, known from the next
@@ -369,37 +439,45 @@ TF_DEVICE void tfk_crs_bwd(const TfLevelArgs& a, int chunk, int tid, bool store_
     const TfLayout& L = a.L;
     const TfCrChunk<BB> ch(L, chunk);
     const int mI = ch.mI, pe = ch.pe, len = ch.len;
-    TF_LDS double sF[NPOS * 5 * B2];
-    TF_LDS double sX[NPOS * BB], sZ[NPOS * BB];
+    TF_LDS double sF[C::FSIZE];
+    TF_LDS double sX[C::VSIZE], sZ[C::VSIZE];
     {
         const double* src = a.crf + (ch.nbase + ch.start) * 5 * B2;
-        for (int i = tid; i < len * 5 * B2; i += NT) sF[5 * B2 + i] = src[i];
+        for (int i = tid; i < len * 5 * B2; i += NT) { const int nd = i / (5 * B2); sF[C::f(nd + 1) + i - nd * 5 * B2] = src[i]; }
         const double* zs = a.zt + (ch.nbase + ch.start) * BB;
         for (int i = tid; i < len * BB; i += NT) sZ[BB + i] = zs[i];
     }
     for (int r = tid; r < BB; r += NT) {
         const double xs = a.xnext[((int64_t)ch.e * a.Lnext.N + ch.p) * BB + r];
-        sX[pe * BB + r] = xs;
+        sX[C::v(pe, r)] = xs;
         a.x[(ch.nbase + ch.node(pe)) * BB + r] = xs;
-        sX[r] = ch.has_prev ? a.xnext[((int64_t)ch.e * a.Lnext.N + ch.pprev) * BB + r] : 0.0;
-        if (store_prev && ch.has_prev) a.x[(ch.nbase + ch.gprev) * BB + r] = sX[r];
+        sX[C::v(0, r)] = ch.has_prev ? a.xnext[((int64_t)ch.e * a.Lnext.N + ch.pprev) * BB + r] : 0.0;
+        if (store_prev && ch.has_prev) a.x[(ch.nbase + ch.gprev) * BB + r] = sX[C::v(0, r)];
     }
     TF_BARRIER();
-    int s = 1;
-    while (2 * s <= mI) s <<= 1;
-    for (; s >= 1; s >>= 1) {
-        const int nA = (mI / s + 1) / 2;
-        for (int j = tid; j < nA; j += NT) {
-            const int k = s * (2 * j + 1);
-            const int kl = k - s, kr = k + s <= mI ? k + s : pe;
-            double E[BB][BB], F[BB][BB], xl[BB], xr[BB], xk[BB];
-            tf_ld_blk<BB>(E, sF + k * 5 * B2 + B2); tf_ld_blk<BB>(F, sF + k * 5 * B2 + 2 * B2);
+    // (rounds of at most 64 tasks by the first wavefront alone: see tfk_crs_fwd)
+    constexpr int WS = NT > 64 ? 64 : NT;
+    bool alone = false;
+    int r = 0;
+    while ((2 << r) <= mI) ++r;
+    for (; r >= 0; --r) {
+        const int s = 1 << r, nA = ((mI >> r) + 1) >> 1;
+        const bool solo = NT > 64 && nA <= 64;
+        if (!solo && alone) { TF_BARRIER(); alone = false; }
+        const int st = solo ? WS : NT;
+        if (!solo || tid < WS)
+            for (int j = tid; j < nA; j += st) {
+                const int k = s * (2 * j + 1);
+                const int kl = k - s, kr = k + s <= mI ? k + s : pe;
+                double E[BB][BB], F[BB][BB], xl[BB], xr[BB], xk[BB];
+                tf_ld_blk<BB>(E, sF + C::f(k) + B2); tf_ld_blk<BB>(F, sF + C::f(k) + 2 * B2);
 #pragma unroll
-            for (int r = 0; r < BB; ++r) { xk[r] = sZ[k * BB + r]; xl[r] = sX[kl * BB + r]; xr[r] = sX[kr * BB + r]; }
-            tf_mv_sub<BB>(xk, E, xl); tf_mv_sub<BB>(xk, F, xr);
+                for (int q = 0; q < BB; ++q) { xk[q] = sZ[C::v(k, q)]; xl[q] = sX[C::v(kl, q)]; xr[q] = sX[C::v(kr, q)]; }
+                tf_mv_sub<BB>(xk, E, xl); tf_mv_sub<BB>(xk, F, xr);
 #pragma unroll
-            for (int r = 0; r < BB; ++r) { sX[k * BB + r] = xk[r]; a.x[(ch.nbase + ch.node(k)) * BB + r] = xk[r]; }
-        }
-        TF_BARRIER();
+                for (int q = 0; q < BB; ++q) { sX[C::v(k, q)] = xk[q]; a.x[(ch.nbase + ch.node(k)) * BB + q] = xk[q]; }
+            }
+        if (solo) { TF_WAVE_SYNC(); alone = true; } else TF_BARRIER();
     }
+    if (alone) TF_BARRIER();
 }

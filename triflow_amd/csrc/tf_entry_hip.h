@@ -101,28 +101,13 @@ __global__ void TF_SWEEP_ATTR __launch_bounds__(TF_SWEEP_BLOCK) tfk_sweep_fj_bdf
     tfk_sweep_body<true, false, false, true>(a, TF_GID, blockIdx.y);
 }
 __global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_spmv(TfSpmvArgs a) {
-    tfk_spmv_body<false>(a, TF_GID, blockIdx.y);
+    tfk_spmv_body(a, TF_GID, blockIdx.y);
 }
-// the same product plus the backward-error monitor of the previous solve (TfSpmvArgs::mon_rhs)
 // running maximum kept as the bit pattern of a non-negative double.  The value only grows, so
 // a wavefront whose candidate is not above what is already there skips the atomic (tens of
 // thousands of same-address atomics otherwise: tfk_berr 72 -> 41 us, profiles/README.md).
 __device__ __forceinline__ void tf_raise_max(unsigned long long* red, unsigned long long bits) {
     if (bits > __atomic_load_n(red, __ATOMIC_RELAXED)) atomicMax(red, bits);
-}
-
-__global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_spmv_mon(TfSpmvArgs a) {
-    const double m = tfk_spmv_body<true>(a, TF_GID, blockIdx.y);
-    {
-        unsigned long long bits = (unsigned long long)__double_as_longlong(m);
-        if (m != m) bits = 0x7ff8000000000000ull;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long o = __shfl_xor(bits, off, 64);
-            bits = o > bits ? o : bits;
-        }
-        if ((threadIdx.x & 63) == 0) tf_raise_max((unsigned long long*)a.mon_red, bits);
-    }
 }
 
 // ---- plane algebra: grid-stride, 16 B per lane where the planes allow ------
@@ -358,6 +343,106 @@ __global__ void __launch_bounds__(TF_CR_BLOCK) tfk_cr_bwd(TfLevelArgs a) {
     else if constexpr (TF_B2 <= 8) tfk_cr_bwd_coop<TF_B2>(a);
 }
 // the last two levels of a solve: one workgroup per system (3 <= b <= 8; the host only launches it there)
+// ---- 3 <= b <= 6: level 1 and the first cyclic-reduction level of a solve in one launch each way
+// (round 4; TfTailArgs: lv[0] = level 1, lv[1] = level 2).  The workgroup idea of tfk_s_fwd / tfk_s_bwd
+// for the multi-variable models: workgroup q owns four 16-node chunks of level 2 and the <= 64 level-1
+// chunks whose separators are their nodes.  Forward: wavefront 0 walks those chunks down, wavefront 1
+// walks up the chunks one further on (the walks that end below the owned separators), both assemble
+// their halves of the separators' right-hand sides (a.fuse_asm), and after a barrier each wavefront
+// reduces two of the four chunks (tfk_cr_fwd_chunk: the body of tfk_cr_fwd) -- no tfk_cr_fwd launch for
+// level 2, no round trip of its right-hand side.  Backward: each wavefront back-substitutes two of the
+// chunks (tfk_cr_bwd_run), the separator above the first one is a level-3 node and is written by this
+// workgroup too, then the launch goes on as tfk_l1_fwd2_backsub.
+__device__ __forceinline__ void tf_own4(const TfLayout& L2, int blk, int& e, int& q0, int& nq, int& c0, int& cnt) {
+    const int qps = (L2.P + 3) / 4;                 // workgroups per system
+    e = blk / qps;
+    q0 = (blk - e * qps) * 4;
+    nq = L2.P - q0 < 4 ? L2.P - q0 : 4;
+    c0 = tf_start(L2, q0);
+    cnt = tf_start(L2, q0 + nq - 1) + tf_len(L2, q0 + nq - 1) - c0;     // <= 64 (chunks of <= 16 nodes)
+}
+__global__ void TF_L1_ATTR __launch_bounds__(128) tfk_l1_solve_cr(TfTailArgs t) {
+    if constexpr (TF_B2 >= 3 && TF_B2 <= 6) {
+        const TfLevelArgs& l1 = t.lv[0];
+        const TfLevelArgs& l2 = t.lv[1];
+        __shared__ TfCrSolveLds<TF_B2> sh[2];
+        const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+        int e, q0, nq, c0, cnt;
+        tf_own4(l2.L, (int)blockIdx.x, e, q0, nq, c0, cnt);
+        const int P1 = l1.L.P;
+        // this wavefront's chunks of level 2: k = w and k = w + 2.  The rows of the first one's stored
+        // reduction are requested before the walks (they do not depend on the right-hand side) ...
+        const TfCrChunk<TF_B2> cha(l2.L, e * l2.L.P + q0 + (w < nq ? w : 0));
+        const TfCrChunk<TF_B2> chb(l2.L, e * l2.L.P + q0 + (w + 2 < nq ? w + 2 : 0));
+        const TfCrIo<TF_B2> ioa(l2, cha), iob(l2, chb);
+        TfCrFwdRows<TF_B2> ra, rb;
+        TF_STAMP(l2, 57);
+        tfk_cr_fwd_load<TF_B2>(cha, lane, ioa, ra);
+        if (lane < cnt) {
+            if (w == 0) tfk_chunk_body<TfRowsL1, +1, false, false, true>(l1, e * P1 + c0 + lane);
+            else {
+                int c = c0 + lane + 1;
+                if (c == P1) c = l1.L.periodic ? 0 : -1;
+                if (c >= 0) tfk_chunk_body<TfRowsL1, -1, false, false, false>(l1, e * P1 + c);
+            }
+        }
+        TF_STAMP(l2, 58);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        TF_STAMP(l2, 59);
+        // ... the right-hand side records the walks left, of both chunks, and the second one's rows now:
+        // one wait for memory, not one per chunk
+        double ya[TF_CR_NYS(TF_B2)], yb[TF_CR_NYS(TF_B2)];
+        tfk_cr_fwd_load_ys<TF_B2>(cha, lane, ioa, ya);
+        tfk_cr_fwd_load_ys<TF_B2>(chb, lane, iob, yb);
+        tfk_cr_fwd_load<TF_B2>(chb, lane, iob, rb);
+        if (w < nq) tfk_cr_fwd_chunk<TF_B2, false, true>(l2, cha, lane, sh[w], ioa, nullptr, &ra, ya);
+        TF_STAMP(l2, 60);
+        if (w + 2 < nq) tfk_cr_fwd_chunk<TF_B2, false, true>(l2, chb, lane, sh[w], iob, nullptr, &rb, yb);
+        TF_STAMP(l2, 61);
+    }
+}
+__global__ void TF_L1_ATTR __launch_bounds__(128) tfk_l1_fwd2_backsub_cr(TfTailArgs t) {
+    if constexpr (TF_RESPIKE_MODEL(TF_MP, TF_NVAR) && TF_B2 >= 3 && TF_B2 <= 6) {
+        extern __shared__ double tf_dyn_lds[];
+        const TfLevelArgs& a = t.lv[0];
+        const TfLevelArgs& l2 = t.lv[1];
+        __shared__ TfCrSolveLds<TF_B2> sh[2];
+        const int lane = threadIdx.x & 63, dir = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+        int e, q0, nq, c0, cnt;
+        tf_own4(l2.L, (int)blockIdx.x, e, q0, nq, c0, cnt);
+        // this wavefront's chunks of level 2 (k = dir, dir + 2): everything they read is requested at once
+        const TfCrChunk<TF_B2> cha(l2.L, e * l2.L.P + q0 + (dir < nq ? dir : 0));
+        const TfCrChunk<TF_B2> chb(l2.L, e * l2.L.P + q0 + (dir + 2 < nq ? dir + 2 : 0));
+        const TfCrIo<TF_B2> ioa(l2, cha), iob(l2, chb);
+        TfCrBwdRows<TF_B2> ra, rb;
+        TF_STAMP(l2, 62);
+        tfk_cr_bwd_load<TF_B2>(l2, cha, lane, ioa, ra, true);
+        const double xa = tfk_cr_bwd_sep<TF_B2>(lane, ioa);
+        tfk_cr_bwd_load<TF_B2>(l2, chb, lane, iob, rb, true);
+        const double xb = tfk_cr_bwd_sep<TF_B2>(lane, iob);
+        if (dir < nq) {
+            // (the separator above the first owned chunk: known from level 3, wanted by the first walk)
+            if (dir == 0 && cha.has_prev && lane >= TfCr<TF_B2>::G && lane < TfCr<TF_B2>::G + TF_B2)
+                l2.x[(cha.nbase + cha.gprev) * TF_B2 + lane - TfCr<TF_B2>::G] = xa;
+            tfk_cr_bwd_run<TF_B2, false, true>(l2, cha, lane, sh[dir], ioa, ra, nullptr, xa);
+        }
+        if (dir + 2 < nq) tfk_cr_bwd_run<TF_B2, false, true>(l2, chb, lane, sh[dir], iob, rb, nullptr, xb);
+        TF_STAMP(l2, 63);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int pg = lane < cnt ? e * a.L.P + c0 + lane : a.L.Ptot;          // (beyond the owned chunks: nothing to do)
+        double* ydn = tf_dyn_lds + lane;
+        double* yup = tf_dyn_lds + (size_t)a.ylds_rows * TF_NVAR * 64 + lane;
+        if (dir == 0) tfk_chunk_body<TfRowsL1, +1, false, false, true, true, true>(a, pg, ydn);
+        else tfk_chunk_body<TfRowsL1, -1, false, false, true, true, true>(a, pg, yup);
+        __syncthreads();
+        tfk_backsub_twist_body<TfRowsL1, true>(a, pg, dir, ydn, yup);
+    }
+}
+
 // ---- b <= 2: a solve in two launches (TfScalarArgs).  As six launches (walks, two forward levels, two
 // backward levels, back-substitution) config 2 spent 41 us in them for 50 MB of traffic: every launch
 // is a round trip to memory for what the previous one left and 4-14 us of one wavefront's latency.
@@ -375,22 +460,44 @@ __global__ void __launch_bounds__(512) tfk_s_fwd(TfScalarArgs t) {
         const TfCrChunk<TF_B2> ch(l2.L, (int)blockIdx.x);
         const int P1 = l1.L.P;
         // the stored reductions of this level-2 chunk and of level 3's one chunk: requested before the
-        // walks (they do not depend on the right-hand side), so that neither level waits for memory
-        __shared__ double sF2[(TF_CRS_MAXLEN + 1) * 5 * TF_B2 * TF_B2], sF3[(TF_CRS_MAXLEN + 1) * 5 * TF_B2 * TF_B2];
-        tfk_crs_stage<TF_B2, 512>(l2, (int)blockIdx.x, tid, sF2);
-        tfk_crs_stage<TF_B2, 512>(t.lv[2], ch.e, tid, sF3);
+        // walks (they do not depend on the right-hand side) and put into LDS after them, so that neither
+        // the walks nor the levels wait for memory (put before the walks: 1.8 us of every workgroup)
+        __shared__ double sF2[TfCrs<TF_B2>::FSIZE], sF3[TfCrs<TF_B2>::FSIZE];
+        TF_STAMP(l2, 57);
+        TF_STAMP_REAL(l2, 30);
+        TfCrsStaged<TF_B2, 512> rF2, rF3;
+        tfk_crs_stage_request<TF_B2, 512>(l2, (int)blockIdx.x, tid, rF2);
+        tfk_crs_stage_request<TF_B2, 512>(t.lv[2], ch.e, tid, rF3);
+        // (thread 0: the inverse of the folded top block, for whichever workgroup solves level 3)
+        double topv[TF_B2 * TF_B2];
+#pragma unroll
+        for (int i = 0; i < TF_B2 * TF_B2; ++i) topv[i] = tid == 0 ? t.lv[2].topAinv[(int64_t)i * t.lv[2].L.Ptot + ch.e] : 0.0;
+        TF_STAMP(l2, 58);
+        // the walks leave their halves of the level-2 right-hand side in LDS, not in memory: nobody else
+        // reads these records, and reading them back took a round trip to the L2 (the walks address them
+        // through TfLevelArgs::rhsnext: a generic pointer placed so that this chunk's first node is sRhs[0])
+        __shared__ double sRhs[TF_CRS_MAXLEN * 2 * TF_B2];
+        TfLevelArgs l1w = l1;
+        l1w.rhsnext = (double*)sRhs - ((int64_t)ch.e * l1.Lnext.N + ch.start) * 2 * TF_B2;
         if (tid < 256) {
-            if (tid < ch.len) tfk_chunk_body<TfRowsL1, +1, false, false, true>(l1, ch.e * P1 + ch.start + tid);
+            if (tid < ch.len) tfk_chunk_body<TfRowsL1, +1, false, false, true>(l1w, ch.e * P1 + ch.start + tid);
         } else if (tid - 256 < ch.len) {
             int c = ch.start + tid - 256 + 1;                       // the chunk whose up walk ends below node c - 1
             if (c == P1) c = l1.L.periodic ? 0 : -1;
-            if (c >= 0) tfk_chunk_body<TfRowsL1, -1, false, false, false>(l1, ch.e * P1 + c);
+            if (c >= 0) tfk_chunk_body<TfRowsL1, -1, false, false, false>(l1w, ch.e * P1 + c);
+            else if (TF_B2 > 0) {
+                // (clamped, the last chunk: no walk comes up to its separator -- its half is zero)
+#pragma unroll
+                for (int r = 0; r < TF_B2; ++r) sRhs[(tid - 256) * 2 * TF_B2 + TF_B2 + r] = 0.0;
+            }
         }
-        // the level-2 right-hand side records of this chunk's nodes were written by this workgroup
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        tfk_crs_stage_put<TF_B2, 512>(l2, (int)blockIdx.x, tid, rF2, sF2);
+        tfk_crs_stage_put<TF_B2, 512>(t.lv[2], ch.e, tid, rF3, sF3);
+        TF_STAMP(l2, 59);
         __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        tfk_crs_fwd<TF_B2, 512, true, true>(l2, (int)blockIdx.x, tid, sF2);
+        TF_STAMP(l2, 60);
+        tfk_crs_fwd<TF_B2, 512, true, true>(l2, (int)blockIdx.x, tid, sF2, sRhs);
+        TF_STAMP(l2, 61);
         // ---- the workgroup of this system that arrives last solves level 3.  What changes hands between
         // workgroups is this chunk's share of level 3's right-hand side, 2 b doubles: stored with
         // agent-scope (write-through) stores by one wavefront, which waits for them and then counts
@@ -409,7 +516,12 @@ __global__ void __launch_bounds__(512) tfk_s_fwd(TfScalarArgs t) {
             }
         }
         __syncthreads();
-        if (last) tfk_crs_fwd<TF_B2, 512, true, false, true>(t.lv[2], ch.e, tid, sF3);
+        TF_STAMP(l2, 62);
+        TF_STAMP_IF(l2, 55, last);
+        TF_STAMP_REAL_IF(l2, 32, last);
+        if (last) tfk_crs_fwd<TF_B2, 512, true, false, true, true>(t.lv[2], ch.e, tid, sF3, nullptr, topv);
+        TF_STAMP_IF(l2, 56, last);
+        TF_STAMP_REAL_IF(l2, 31, last);
     }
 }
 __global__ void __launch_bounds__(512) tfk_s_bwd(TfScalarArgs t) {
@@ -418,11 +530,15 @@ __global__ void __launch_bounds__(512) tfk_s_bwd(TfScalarArgs t) {
         const TfLevelArgs& l2 = t.lv[1];
         const int tid = threadIdx.x;
         const TfCrChunk<TF_B2> ch(l2.L, (int)blockIdx.x);
+        TF_STAMP(l2, 50);
         tfk_crs_bwd<TF_B2, 512>(l2, (int)blockIdx.x, tid, true);
+        TF_STAMP(l2, 51);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        TF_STAMP(l2, 52);
         if (tid < ch.len) tfk_backsub_body<TfRowsL1, true>(l1, ch.e * l1.L.P + ch.start + tid);
+        TF_STAMP(l2, 53);
     }
 }
 __global__ void __launch_bounds__(64 * TF_CR_TAIL_WAVES) tfk_cr_tail(TfTailArgs t) {

@@ -48,6 +48,9 @@
         (a).stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #define TF_STAMP_REAL(a, i) do { if ((a).stamps && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) \
         (a).stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// ... by whichever workgroup satisfies `cond` (the last arriver of a hand-off)
+#define TF_STAMP_IF(a, i, cond) do { if ((a).stamps && (cond) && threadIdx.x == 0) (a).stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TF_STAMP_REAL_IF(a, i, cond) do { if ((a).stamps && (cond) && threadIdx.x == 0) (a).stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 // ... and event counters (every workgroup; one lane per wavefront counts)
 #define TF_COUNT(a, i) do { if ((a).stamps && (threadIdx.x & 63) == 0) atomicAdd(&(a).stamps[i], 1ull); } while (0)
 // ... and begin / end times (100 MHz) of every workgroup of a level-1 kernel: region k of 2048
@@ -63,6 +66,8 @@
 #define TF_STAMP(a, i) do {} while (0)
 #define TF_STAMP_T(a, i, tid) do {} while (0)
 #define TF_STAMP_REAL(a, i) do {} while (0)
+#define TF_STAMP_IF(a, i, cond) do {} while (0)
+#define TF_STAMP_REAL_IF(a, i, cond) do {} while (0)
 #define TF_COUNT(a, i) do {} while (0)
 #endif
 
@@ -314,17 +319,13 @@ TF_DEVICE void tfk_sweep_body(const TfSweepArgs& a, int pg, int seg) {
 // 2. y = scale * (J @ v)      (CSC product of schemes.py:157, 553; the column
 //    of a stored value is the clamped / wrapped neighbour, compilers.py:303-328)
 // ===========================================================================
-// MON: also the monitor of TfSpmvArgs::mon_rhs; returns this thread's share of it (else 0).
-// A kernel of its own (tfk_spmv_mon): the magnitudes cost registers the plain product keeps free.
-template <bool MON = false>
-TF_DEVICE double tfk_spmv_body(const TfSpmvArgs& a, int pg, int seg) {
+TF_DEVICE void tfk_spmv_body(const TfSpmvArgs& a, int pg, int seg) {
     const TfLayout& L = a.L;
-    if (pg >= L.Ptot) return 0.0;
+    if (pg >= L.Ptot) return;
     const int e = pg / L.P, p = pg - e * L.P;
     const int len = tf_len(L, p);
     const int i0 = seg * TF_SEG;
-    if (i0 >= len) return 0.0;
-    double worst = 0.0;
+    if (i0 >= len) return;
     auto ld = [&](int v, int ii) -> double {
         const int64_t s = (ii >= 0 && ii < len) ? tf_idx(L, pg, ii) : tf_nbr(L, e, p, len, 0, ii);
         if (a.nterms == 0) return a.v[(int64_t)v * L.plane + s];
@@ -350,10 +351,9 @@ TF_DEVICE double tfk_spmv_body(const TfSpmvArgs& a, int pg, int seg) {
                 w[v][TF_W - 1] = ld(v, i + TF_MP);
             }
             const int64_t s = tf_idx(L, pg, i);
-            double acc[TF_NVAR], mag[TF_NVAR];
+            double acc[TF_NVAR];
 #pragma unroll
-            for (int v = 0; v < TF_NVAR; ++v) { acc[v] = 0.0; mag[v] = 0.0; }
-            constexpr bool mon = MON;
+            for (int v = 0; v < TF_NVAR; ++v) acc[v] = 0.0;
             double jr[TF_NNZ > 0 ? TF_NNZ : 1];
             ju.row([&](int k) { return tf_ldp(a.Jv, k, L.plane, (unsigned)s * 8u); }, jr);
 #pragma unroll
@@ -362,31 +362,13 @@ TF_DEVICE double tfk_spmv_body(const TfSpmvArgs& a, int pg, int seg) {
                 double wv = w[tf_pat_var[k]][tf_pat_off[k] + TF_MP];
                 if (a.absval) { jv = tf_abs(jv); wv = tf_abs(wv); }
                 acc[tf_pat_eq[k]] = acc[tf_pat_eq[k]] + jv * wv;
-                if (mon) mag[tf_pat_eq[k]] = tf_fma(tf_abs(jv), tf_abs(wv), mag[tf_pat_eq[k]]);
             }
 #pragma unroll
             for (int v = 0; v < TF_NVAR; ++v)
                 a.y[(int64_t)v * L.plane + s] = a.addF
                     ? a.cF * a.addF[(int64_t)v * L.plane + s] + a.cA * acc[v] : acc[v];
-            if (mon) {
-                // acc = J (g x), mag = |J| |g x|: the residual of (I - cJ) x = b at this node.  The
-                // quotient is only formed where it is above the refinement trigger (rare).
-                const double ag = tf_abs(a.mon_inv_g), ac = tf_abs(a.mon_c);
-#pragma unroll
-                for (int v = 0; v < TF_NVAR; ++v) {
-                    const double b = a.mon_rhs[(int64_t)v * L.plane + s];
-                    const double xv = w[v][TF_MP] * a.mon_inv_g;
-                    const double num = tf_abs((b - xv) + a.mon_c * (acc[v] * a.mon_inv_g));
-                    const double den = tf_abs(xv) + ac * (mag[v] * ag) + tf_abs(b);
-                    if (num > 1e-12 * den || num != num) {
-                        const double q = num / den;
-                        worst = (q > worst || q != q) ? q : worst;
-                    }
-                }
-            }
         }
     }
-    return worst;
 }
 
 // componentwise (Oettli-Prager) backward error of (I - cJ) x = b, one pass over J:

@@ -33,18 +33,21 @@ void step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns, con
     for (int i = 0; i < ns; ++i) {
         if (i > 0) {
             // F(U + sum_j alpha_ij k_j): the stage state is formed inside the sweep.  It goes to a
-            // buffer of its own: F keeps dt*F(U), the right-hand side of stage 0, for the monitor
-            // ... plus dt*(J @ sum_j gamma_ij k_j), in the same pass; for i == 1 the pass (every 8th
-            // factorisation) also measures the backward error of the stage-0 solve (k0 from dt*F(U))
+            // buffer of its own (F keeps dt*F(U), the right-hand side of stage 0)
+            // ... plus dt*(J @ sum_j gamma_ij k_j), in the same pass
             double gs[TF_MAX_TERMS];
             for (int j = 0; j < i; ++j) { ks[j] = s->K[j].p; cs[j] = alpha[i * ns + j]; gs[j] = gamma[i * ns + j]; }
-            s->stage_rhs(Uin, i, ks, cs, gs, dt, s->Wrhs.p, i == 1 ? s->F.p : nullptr);
+            s->stage_rhs(Uin, i, ks, cs, gs, dt, s->Wrhs.p);
         }
         // the last stage of a fixed step of one or two stages: the new state leaves with the solve
         if (i == ns - 1 && ns <= 2 && !(b_pred && want_err))
             s->request_update(U, Uin, ns == 2 ? s->K[0].p : nullptr, b[0], ns == 2 ? b[1] : 0.0, ns);
-        if (i == 0) s->factor_step(gamma[0] * dt, s->F.p, s->K[0].p); // factorise + first stage
-        else s->solve(s->Wrhs.p, s->K[i].p);
+        if (i == 0) {
+            s->factor_step(gamma[0] * dt, s->F.p, s->K[0].p);         // factorise + first stage
+            // the backward error of that solve, (I - gamma dt J) k0 = dt F(U), at one node per chunk: a small
+            // launch nobody waits for, every step between the synchronising checks (monitor_sampled)
+            if (ns > 1 && s->sampled_monitor_due()) s->monitor_sampled(s->F.p, s->K[0].p, nullptr);
+        } else s->solve(s->Wrhs.p, s->K[i].p);
     }
     for (int j = 0; j < ns; ++j) { ks[j] = s->K[j].p; cs[j] = b[j]; }
     const bool updated = s->take_update_done();
@@ -119,7 +122,7 @@ int tf_step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns,
     std::string key = "R|" + std::to_string(src) + ">" + std::to_string(dst) + "|" + bits_of(dt) + "|" +
         std::to_string(ns) + "|" + std::to_string(hook_after) + "|" + std::to_string(s->ndir) + (s->input_is_hooked(src) ? "h" : "c") + "|" +
         std::to_string(s->sweeps_for(gamma[0] * dt)) + "|" + std::to_string(s->refine) + "|" + (b_pred && err_out ? "e" : "-") +
-        (s->will_monitor(gamma[0] * dt) ? "m" : "-") + s->slot_key(gamma[0] * dt);
+        s->slot_key(gamma[0] * dt);
     s->prepare_step(gamma[0] * dt);
     for (int i = 0; i < ns * ns; ++i) key += bits_of(alpha[i]) + bits_of(gamma[i]);
     for (int i = 0; i < ns; ++i) key += bits_of(b[i]) + (b_pred ? bits_of(b_pred[i]) : std::string("-"));

@@ -188,7 +188,7 @@ struct tf_solver {
     struct SlotMeta {
         double factor_c = 0.0, cf_c = 0.0;
         bool have_factor = false, cf_valid = false, fact_checked = false, fact_needs_refine = false,
-             check_now = true, mon_this = false, delegated = false;
+             check_now = true, delegated = false;
         uint64_t cf_ver = 0;
         int sweeps_needed = 0;
     } meta_alt;
@@ -405,17 +405,10 @@ struct tf_solver {
     void sweep_theta(const double* fields, double dt, double theta, double* rhs);
     void spmv(const double* v, double* y, double scale, bool absval = false);
 
-    // y = cF*F + cA*(J @ sum_t vc_t vx_t): stage right-hand side of a ROW scheme in one pass
-    // (every monitor_every-th factorisation: the magnitudes make the pass 40 % slower)
-    bool mon_this = false;         // the factorisation in memory is one the monitor samples (set by factor())
-    bool monitor_due(const double* monitor_rhs, int nterms, const double* vc) const;
-    // will the next factorisation (with this c) be sampled by the monitor?  Halfway between two
-    // explicit checks; refine = -2: every one
-    bool will_monitor(double c);
     // Right-hand side of Rosenbrock stage i >= 1,  dt*F(U + sum_j alpha_ij k_j) + dt*(J @ sum_j gamma_ij k_j):
     // one pass (tfk_sweep_f_stage_rhs) that evaluates F from the window and multiplies J by the other
-    // combination of the same k_j loads.  When the monitor is due, the two-kernel form runs
-    // (tfk_sweep_f_stage, tfk_spmv_mon): same operations, same bits.
+    // combination of the same k_j loads.  (fuse_stage off, TRIFLOW_FUSE_STAGE=0: the two-kernel form,
+    // tfk_sweep_f_stage + tfk_spmv: same operations, same bits.)
     bool fuse_stage = true;
     // Constant matrix (tf_set_constant_jacobian: no Jacobian entry depends on the state or the node).
     // A factorisation made for c stays valid while c, the scalar parameters and dx are what they
@@ -453,10 +446,9 @@ struct tf_solver {
     int* tiny_piv = nullptr;
     TfTinyArgs tiny_args(const double* rhs1, double* x1);
     bool l1_fuse_backsub = true;   // twisted form: tfk_l1_fwd2_backsub (TRIFLOW_L1_FUSE_BACKSUB=0: two launches)
-    void stage_rhs(const double* Uin, int nterms, const double* const* ks, const double* ac, const double* gc, double dt, double* y, const double* monitor_rhs);
-    // monitor_rhs != NULL (first stage product of a Rosenbrock step, one term g*k0): the same pass
-    // measures the backward error of the solve that produced k0 from monitor_rhs (red[4])
-    void spmv_stage(int nterms, const double* const* vx, const double* vc, const double* Fp, double cF, double cA, double* y, const double* monitor_rhs = nullptr);
+    void stage_rhs(const double* Uin, int nterms, const double* const* ks, const double* ac, const double* gc, double dt, double* y);
+    // y = cF*F + cA*(J @ sum_t vc_t vx_t)
+    void spmv_stage(int nterms, const double* const* vx, const double* vc, const double* Fp, double cF, double cA, double* y);
 
     // State a step starts from: the reference copies the fields and applies the hook to
     // the copy (schemes.py:144-145, 548-549); without a hook the source slot is read in place.
@@ -514,6 +506,8 @@ struct tf_solver {
     // is two launches (tfk_s_fwd / tfk_s_bwd, TfScalarArgs) instead of six
     bool s_fuse = true;            // (TRIFLOW_S_FUSE=0: A/B runs, tests)
     unsigned* sfuse_counter = nullptr;
+    bool l1cr_fuse = true;         // (TRIFLOW_L1CR_FUSE=0: A/B runs, tests)
+    bool l1cr_ok() const;
     bool scalar_fused_ok() const;
     TfScalarArgs scalar_args(const double* rhs1, double* x1);
     // The two last levels of a solve go in one launch (tfk_cr_tail) when both are cyclic-reduction
@@ -525,13 +519,14 @@ struct tf_solver {
     // componentwise (Oettli-Prager) backward error
     //   max_i |b - A x|_i / (|x| + |c J||x| + |b|)_i
     double backward_error(const double* rhs1, const double* x1);
-    // The monitor of the Theta and BDF-2 steps (the Rosenbrock steps have theirs inside the J @ v pass
-    // of stage 1, tfk_spmv_mon): between two synchronising checks every new factorisation has the same
+    // The monitor of the steps (Theta, BDF-2, and the stage-0 solve of a Rosenbrock step -- until round 4
+    // every 8th of those measured it inside a two-kernel form of stage 1's right-hand side, 69 us against
+    // this launch's 4): between two synchronising checks every new factorisation has the same
     // backward error measured at ONE node of every level-1 chunk -- a different one in every step, so
     // that every chunk's elimination is probed in every step and every row once per chunk length (32
     // steps) -- with no host wait: a thread per chunk, ~45 loads each (config 5: 45 MB, ~1 % of a step;
     // the full pass is 576 MB).  The maximum goes to red[4] and is looked at by the next synchronising
-    // call, like the Rosenbrock monitor's.
+    // call.
     // xbase: the state the step started from, when x1 is the new state of a step whose solve leaves
     // U + delta instead of delta (TfBerrArgs::xbase).
     unsigned mon_phase = 0;
@@ -572,10 +567,9 @@ struct tf_solver {
     void delegate_solve(const double* rhs1, double* x1);
     void polish(const double* rhs1, double* x1);
 
-    // Between two explicit (synchronising) checks a Rosenbrock step measures the backward error
-    // of its factorisation inside its first J @ v pass (tfk_spmv_mon: no launch of its own, no
-    // synchronisation); with refine = -2 every step does.  The worst value since the last look is
-    // read here, at the synchronising calls.
+    // Between two explicit (synchronising) checks every step measures the backward error of its
+    // factorisation at one node per chunk (monitor_sampled: no synchronisation); with refine = -2 there
+    // are no explicit checks.  The worst value since the last look is read here, at the synchronising calls.
     bool monitored = false;
     // have_flag / have_worst: values that already came back with another download of this call
     void check_status(const int* have_flag = nullptr, const double* have_worst = nullptr);

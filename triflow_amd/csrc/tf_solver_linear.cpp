@@ -53,7 +53,7 @@ void tf_solver::factor(double c, const double* rhs1, double* x1) {
         // this plan is known to break down for such a c: straight to the longer chunks
         ++n_factor;
         have_factor = true; cf_valid = jconst; cf_c = c; cf_ver = par_ver;
-        check_now = false; mon_this = false; fact_checked = true; sweeps_needed = 0;
+        check_now = false; fact_checked = true; sweeps_needed = 0;
         delegate_factor(c);
         if (rhs1) delegate_solve(rhs1, x1);
         return;
@@ -90,7 +90,6 @@ void tf_solver::factor(double c, const double* rhs1, double* x1) {
     cf_valid = jconst; cf_c = c; cf_ver = par_ver;
     const Checked* like = checked_like(c);
     check_now = refine == -1 && (n_factor <= 4 || !like || n_factor - like->at >= berr_cur);
-    mon_this = refine == -2 || (refine == -1 && !check_now && like && n_factor - like->at == berr_cur / 2);
     if (check_now) { fact_checked = false; fact_needs_refine = false; sweeps_needed = 0; }
     else if (like) { sweeps_needed = like->sweeps; fact_needs_refine = sweeps_needed > 0; }
     // (between checks the verdict of the last checked factorisation with such a c stands)
@@ -127,7 +126,17 @@ void tf_solver::backsub_chain(const double* rhs1, double* x1, int skip) {
         launch(TFK_S_BWD, (unsigned)t.lv[1].L.Ptot, 1, 512, &t, sizeof(t));
         return;
     }
+    // level 2 backwards inside the level-1 launch (tfk_l1_fwd2_backsub_cr) where that launch exists
+    bool l2_in_l1 = false;
+    if (l1cr_ok() && levels.size() - (size_t)skip >= 2) {
+        TfLevelArgs a0 = level_args(0, rhs1, x1);
+        // (its cyclic-reduction blocks are static LDS on top of y: where y alone takes a workgroup's half of
+        // the CU -- config 5, 80 KB -- the launch would run one workgroup per CU: 810 -> 719 steps/s)
+        const unsigned lds0 = l1_twist_lds(a0);
+        l2_in_l1 = lds0 > 0 && lds0 <= 64u * 1024u;
+    }
     for (size_t l = levels.size() - (size_t)skip; l-- > 0;) {
+        if (l == 1 && l2_in_l1) continue;
         TfLevelArgs a = level_args(l, rhs1, x1);
         if (l == 0) {
             // (twisted: grid.y = 2, the down and the up half of every chunk, tf_twist_h)
@@ -141,6 +150,13 @@ void tf_solver::backsub_chain(const double* rhs1, double* x1, int skip) {
                     a.upd_c0 = upd_req.c0; a.upd_c1 = upd_req.c1; a.upd_n = upd_req.n;
                     upd_done = true;
                 }
+                if (l2_in_l1) {
+                    TfTailArgs t;
+                    t.lv[0] = a;
+                    t.lv[1] = level_args(1, rhs1, x1);
+                    launch(TFK_L1_FWD2_BACKSUB_CR, (unsigned)nsys * cdiv(t.lv[1].L.P, 4), 1, 128, &t, sizeof(t), lds);
+                    continue;
+                }
                 launch(TFK_L1_FWD2_BACKSUB, cdiv(a.L.Ptot, 64), 1, 128, &a, sizeof(a), lds);
                 continue;
             }
@@ -150,6 +166,13 @@ void tf_solver::backsub_chain(const double* rhs1, double* x1, int skip) {
         else if (levels[l]->cr) launch(TFK_CR_BWD, (unsigned)a.L.Ptot, 1, cr_block(), &a, sizeof(a));
         else launch(TFK_BT_BACKSUB, cdiv((int64_t)a.L.Ptot * tfb::coop_group(levels[l]->B), 64), 1, 64, &a, sizeof(a));
     }
+}
+
+// 3 <= b <= 6 with at least two cyclic-reduction levels above level 2: level 1 and level 2 of a solve in one
+// launch each way (tfk_l1_solve_cr, tfk_l1_fwd2_backsub_cr; the walks must assemble the separator rows)
+bool tf_solver::l1cr_ok() const {
+    return l1cr_fuse && tfb::is_device_build() && !tiny && top.B >= 3 && top.B <= 6 && levels.size() >= 4 &&
+           levels[1]->cr && levels[2]->cr && fuse_asm_ok();
 }
 
 bool tf_solver::scalar_fused_ok() const {
@@ -192,6 +215,14 @@ void tf_solver::solve_once(const double* rhs1, double* x1) {
             launch(TFK_CR_TAIL, (unsigned)nsys, 1, 64u * 8u, &t, sizeof(t));
             backsub_chain(rhs1, x1, 2);
             return;
+        }
+        if (l == 0 && l1cr_ok()) {
+            TfTailArgs t;
+            t.lv[0] = level_args(0, rhs1, x1);
+            t.lv[1] = level_args(1, rhs1, x1);
+            launch(TFK_L1_SOLVE_CR, (unsigned)nsys * cdiv(t.lv[1].L.P, 4), 1, 128, &t, sizeof(t));
+            l = 1;                                    // (level 2's forward elimination went with it)
+            continue;
         }
         TfLevelArgs a = level_args(l, rhs1, x1);
         unsigned gx = cdiv(a.L.Ptot, 64);

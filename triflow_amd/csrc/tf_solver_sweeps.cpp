@@ -104,16 +104,6 @@ void tf_solver::spmv(const double* v, double* y, double scale, bool absval) {
     launch(TFK_SPMV, gx, gy, spec.sweep_block, &a, sizeof(a));
 }
 
-bool tf_solver::monitor_due(const double* monitor_rhs, int nterms, const double* vc) const {
-    return monitor_rhs && nterms == 1 && vc[0] != 0.0 && refine < 0 && !reused && mon_this;
-}
-
-bool tf_solver::will_monitor(double c) {
-    if (refine == -2) return true;
-    const Checked* like = checked_like(c);
-    return refine == -1 && !check_due(c) && like && n_factor + 1 - like->at == berr_cur / 2;
-}
-
 bool tf_solver::alt_ok(double c) const {
     return jconst && alt_allocated && meta_alt.cf_valid && have_jac && same_c(meta_alt.cf_c, c) && meta_alt.cf_ver == par_ver;
 }
@@ -143,10 +133,10 @@ void tf_solver::swap_slots() {
     SlotMeta cur;
     cur.factor_c = factor_c; cur.cf_c = cf_c; cur.have_factor = have_factor; cur.cf_valid = cf_valid;
     cur.fact_checked = fact_checked; cur.fact_needs_refine = fact_needs_refine; cur.check_now = check_now;
-    cur.mon_this = mon_this; cur.cf_ver = cf_ver; cur.sweeps_needed = sweeps_needed; cur.delegated = delegated;
+    cur.cf_ver = cf_ver; cur.sweeps_needed = sweeps_needed; cur.delegated = delegated;
     factor_c = meta_alt.factor_c; cf_c = meta_alt.cf_c; have_factor = meta_alt.have_factor; cf_valid = meta_alt.cf_valid;
     fact_checked = meta_alt.fact_checked; fact_needs_refine = meta_alt.fact_needs_refine; check_now = meta_alt.check_now;
-    mon_this = meta_alt.mon_this; cf_ver = meta_alt.cf_ver; sweeps_needed = meta_alt.sweeps_needed; delegated = meta_alt.delegated;
+    cf_ver = meta_alt.cf_ver; sweeps_needed = meta_alt.sweeps_needed; delegated = meta_alt.delegated;
     meta_alt = cur;
     slot_id ^= 1;
 }
@@ -175,10 +165,10 @@ TfTinyArgs tf_solver::tiny_args(const double* rhs1, double* x1) {
     return t;
 }
 
-void tf_solver::stage_rhs(const double* Uin, int nterms, const double* const* ks, const double* ac, const double* gc, double dt, double* y, const double* monitor_rhs) {
-    if (!fuse_stage || monitor_due(monitor_rhs, nterms, gc)) {
+void tf_solver::stage_rhs(const double* Uin, int nterms, const double* const* ks, const double* ac, const double* gc, double dt, double* y) {
+    if (!fuse_stage) {
         sweep(Uin, false, nterms, ks, ac, 1.0, Wstage.p);
-        spmv_stage(nterms, ks, gc, Wstage.p, dt, dt, y, monitor_rhs);
+        spmv_stage(nterms, ks, gc, Wstage.p, dt, dt, y);
         return;
     }
     TfSweepArgs a;
@@ -192,21 +182,16 @@ void tf_solver::stage_rhs(const double* Uin, int nterms, const double* const* ks
     launch(nterms >= 2 && nterms <= 5 ? TFK_SWEEP_F_STAGE_RHS_N : TFK_SWEEP_F_STAGE_RHS, gx, gy, spec.sweep_block, &a, sizeof(a));
 }
 
-void tf_solver::spmv_stage(int nterms, const double* const* vx, const double* vc, const double* Fp, double cF, double cA, double* y, const double* monitor_rhs) {
+void tf_solver::spmv_stage(int nterms, const double* const* vx, const double* vc, const double* Fp, double cF, double cA, double* y) {
     TfSpmvArgs a;
     std::memset(&a, 0, sizeof(a));
-    const bool mon = monitor_due(monitor_rhs, nterms, vc);
-    if (mon) {
-        a.mon_rhs = monitor_rhs; a.mon_c = factor_c; a.mon_inv_g = 1.0 / vc[0]; a.mon_red = red.p + 4;
-        monitored = true;
-    }
     a.L = L1; a.Jv = Jv.p; a.v = nullptr; a.y = y; a.scale = 1.0;
     a.parsca = parsca.p; a.dx = dx.p;
     a.nterms = nterms;
     for (int t = 0; t < nterms; ++t) { a.vx[t] = vx[t]; a.vc[t] = vc[t]; }
     a.addF = Fp; a.cF = cF; a.cA = cA;
     unsigned gx = sweep_gx(), gy = cdiv(L1.M, spec.seg);
-    launch(mon ? TFK_SPMV_MON : TFK_SPMV, gx, gy, spec.sweep_block, &a, sizeof(a));
+    launch(TFK_SPMV, gx, gy, spec.sweep_block, &a, sizeof(a));
 }
 
 void tf_solver::mark_hooked(int slot, bool post) {
