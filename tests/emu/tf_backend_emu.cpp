@@ -100,6 +100,11 @@ void launch(Module*, int kernel, unsigned gx, unsigned gy, unsigned block,
         double m = *a.red;
         for (int64_t i = 0; i < a.n; ++i) { double v = a.op == TF_VEC_MAXRATIO ? tf_vec_ratio(a, i) : (a.op == TF_VEC_SUM_ERR ? tf_vec_sum_err(a, i) : tf_vec_err(a, i)); m = (v > m || v != v) ? v : m; }
         *a.red = m; } break;
+    case TFK_SWEEP_F_STAGE_RHS_MON: { const auto& a = *(const TfStageMonArgs*)args;
+        for (unsigned y = 0; y + 1 < gy; ++y) for (int64_t t = 0; t < nthreads; ++t) tfk_sweep_body<false, true, false, false, true, TF_STAGE_SEG>(a.s, (int)t, (int)y);
+        double m = *a.b.red;
+        for (int64_t t = 0; t < nthreads; ++t) { double v = tfk_berr_body(a.b, (int)t, 0); m = (v > m || v != v) ? v : m; }
+        *a.b.red = m; } break;
     case TFK_BERR: { const auto& a = *(const TfBerrArgs*)args;
         double m = *a.red;
         for (unsigned y = 0; y < gy; ++y) for (int64_t t = 0; t < nthreads; ++t) {

@@ -1298,6 +1298,7 @@ def check_theta_bdf2_monitor(backend):
         ens.close()
 
 
+
 def check_ensemble_equals_single_members(backend, N=3000, nsys=3, steps=3, exact=True, **opts):
     """nsys members stepped together in one solver (per-member scalar parameters and
     initial conditions) give, member by member, the bits of nsys separate single-member

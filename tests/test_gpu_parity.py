@@ -735,11 +735,12 @@ def test_adaptive_landing_reuse():
 
 
 @pytest.mark.parametrize("name,N", [("M2_diff", 20011), ("kdv", 70003), ("burgers", 5003), ("bivar", 9001),
-                                    ("M1_advdiff", 300007)])
+                                    ("M1_advdiff", 300007), ("M2_diff", 1500007)])
 def test_scalar_solve_in_two_launches(name, N, monkeypatch):
     """b = mp * nvar <= 2 with the plan [level 1 | 256-node chunks | one chunk]: tfk_s_fwd / tfk_s_bwd run
     the kernels' bodies of the six-launch solve in two launches -- the same operations, the same bits;
-    against SuperLU as well; periodic and clamped; a solve that rides with the factorisation and later ones."""
+    against SuperLU as well; periodic and clamped; a solve that rides with the factorisation and later ones.
+    (N = 1.5e6: a last level of one 367-node chunk, TF_CRS_TOPLEN.)"""
     m, mo = pc.device_model(name, HIP), pc.oracle_model(name)
     rng = np.random.default_rng(11)
     for periodic in (True, False):

@@ -117,6 +117,10 @@ struct TfBerrArgs {               // componentwise backward error of (I - cJ) x 
     const double* xbase;
 };
 
+// tfk_sweep_f_stage_rhs_mon: the stage pass and, as one more row of workgroups, the sampled backward-error
+// probe of the solve before it (TfBerrArgs::one_node >= 0)
+struct TfStageMonArgs { TfSweepArgs s; TfBerrArgs b; };
+
 struct TfVecArgs {                 // elementwise plane algebra
     int64_t n;                     // elements (nvar * plane)
     int nterms;
@@ -319,6 +323,8 @@ struct TfTopArgs {                 // final 1-node system per ensemble member
 #define TF_CR_MAXLEN 16
 // ... and of the scalar variant (b <= 2: one thread per node, 256-thread workgroups)
 #define TF_CRS_MAXLEN 256
+// ... and of a level that is ONE chunk per system (a 1 x 1 block's records fit the LDS twice as long)
+#define TF_CRS_TOPLEN(b) ((b) == 1 ? 512 : 256)
 
 // Kernel table: index = launch id used by the runtime, name = entry point in
 // the per-model code object (tf_entry_hip.h).
@@ -329,7 +335,7 @@ enum TfKernel {
     TFK_TOP_FACTOR, TFK_TOP_SOLVE, TFK_BERR, TFK_DIFFNORM, TFK_L1_FACTOR_RHS, TFK_SWEEP_F_STAGE,
     TFK_CR_FACTOR, TFK_CR_FWD, TFK_CR_BWD, TFK_POKE, TFK_SWEEP_FJ_THETA, TFK_SWEEP_FJ_BDF2, TFK_GATHER,
     TFK_SWEEP_F_STAGE_RHS, TFK_L1_FWD2, TFK_L1_BACKSUB_U, TFK_CR_TAIL, TFK_L1_FWD2_BACKSUB, TFK_TINY_FACTOR, TFK_TINY_SOLVE,
-    TFK_S_FWD, TFK_S_BWD, TFK_SWEEP_F_STAGE_RHS_N, TFK_L1_SOLVE_CR, TFK_L1_FWD2_BACKSUB_CR, TFK_COUNT
+    TFK_S_FWD, TFK_S_BWD, TFK_SWEEP_F_STAGE_RHS_N, TFK_L1_SOLVE_CR, TFK_L1_FWD2_BACKSUB_CR, TFK_SWEEP_F_STAGE_RHS_MON, TFK_COUNT
 };
 #define TF_KERNEL_NAMES { \
     "tfk_sweep_f", "tfk_sweep_fj", "tfk_spmv", "tfk_vec", "tfk_vec_maxabs", "tfk_perm", "tfk_dirichlet", \
@@ -339,4 +345,4 @@ enum TfKernel {
     "tfk_cr_factor", "tfk_cr_fwd", "tfk_cr_bwd", "tfk_poke", "tfk_sweep_fj_theta", "tfk_sweep_fj_bdf2", \
     "tfk_gather", "tfk_sweep_f_stage_rhs", "tfk_l1_fwd2", "tfk_l1_backsub_u", "tfk_cr_tail", \
     "tfk_l1_fwd2_backsub", "tfk_tiny_factor", "tfk_tiny_solve", "tfk_s_fwd", "tfk_s_bwd", "tfk_sweep_f_stage_rhs_n", \
-    "tfk_l1_solve_cr", "tfk_l1_fwd2_backsub_cr" }
+    "tfk_l1_solve_cr", "tfk_l1_fwd2_backsub_cr", "tfk_sweep_f_stage_rhs_mon" }

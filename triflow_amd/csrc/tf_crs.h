@@ -56,7 +56,7 @@ struct TfCrChunk {
 // per 256-thread workgroup, 8 rounds, levels shrink 256x (N = 1e6: 31250 -> 123 -> 1
 // chunks, where the chunk walks needed 6 levels of three kernels each).
 template <int BB> struct TfCrs {
-    static constexpr int MAXLEN = TF_CRS_MAXLEN, NPOS = MAXLEN + 1;
+    static constexpr int MAXLEN = TF_CRS_TOPLEN(BB), NPOS = MAXLEN + 1;
     // LDS places of the solve kernels (tfk_crs_fwd / tfk_crs_bwd): a vector [pos][b], records [pos][5][b][b].
     // (Padding them against the bank conflicts of the power-of-two strides of the rounds changed nothing:
     // a round is bound by the instructions one wavefront issues, profiles/r04_scalar_stamps.txt.)
@@ -258,19 +258,19 @@ TF_DEVICE void tfk_crs_stage(const TfLevelArgs& a, int chunk, int tid, double* s
 }
 // ... in two parts, for a caller with work to do while the loads are in flight: request (into registers),
 // then put into LDS
-template <int BB, int NT> struct TfCrsStaged { double v[(TF_CRS_MAXLEN * 5 * BB * BB + NT - 1) / NT]; };
-template <int BB, int NT>
-TF_DEVICE void tfk_crs_stage_request(const TfLevelArgs& a, int chunk, int tid, TfCrsStaged<BB, NT>& regs) {
+template <int BB, int NT, int LEN> struct TfCrsStaged { double v[(LEN * 5 * BB * BB + NT - 1) / NT]; };
+template <int BB, int NT, int LEN>
+TF_DEVICE void tfk_crs_stage_request(const TfLevelArgs& a, int chunk, int tid, TfCrsStaged<BB, NT, LEN>& regs) {
     const TfCrChunk<BB> ch(a.L, chunk);
     const double* src = a.crf + (ch.nbase + ch.start) * 5 * BB * BB;
-    constexpr int NQ = (TF_CRS_MAXLEN * 5 * BB * BB + NT - 1) / NT;
+    constexpr int NQ = (LEN * 5 * BB * BB + NT - 1) / NT;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) regs.v[q] = tid + q * NT < ch.len * 5 * BB * BB ? src[tid + q * NT] : 0.0;
 }
-template <int BB, int NT>
-TF_DEVICE void tfk_crs_stage_put(const TfLevelArgs& a, int chunk, int tid, const TfCrsStaged<BB, NT>& regs, double* sF) {
+template <int BB, int NT, int LEN>
+TF_DEVICE void tfk_crs_stage_put(const TfLevelArgs& a, int chunk, int tid, const TfCrsStaged<BB, NT, LEN>& regs, double* sF) {
     const TfCrChunk<BB> ch(a.L, chunk);
-    constexpr int NQ = (TF_CRS_MAXLEN * 5 * BB * BB + NT - 1) / NT;
+    constexpr int NQ = (LEN * 5 * BB * BB + NT - 1) / NT;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int i = tid + q * NT, nd = i / (5 * BB * BB);

@@ -142,8 +142,7 @@ __global__ void __launch_bounds__(256) tfk_vec_maxabs(TfVecArgs a) {
     }
 }
 
-__global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_berr(TfBerrArgs a) {
-    const double m = tfk_berr_body(a, TF_GID, blockIdx.y);
+__device__ __forceinline__ void tf_berr_reduce(const TfBerrArgs& a, double m) {
     unsigned long long bits = (unsigned long long)__double_as_longlong(m);
     if (m != m) bits = 0x7ff8000000000000ull;
 #pragma unroll
@@ -152,6 +151,16 @@ __global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_berr(TfBerrArgs a) {
         bits = o > bits ? o : bits;
     }
     if ((threadIdx.x & 63) == 0) tf_raise_max((unsigned long long*)a.red, bits);
+}
+__global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_berr(TfBerrArgs a) {
+    tf_berr_reduce(a, tfk_berr_body(a, TF_GID, blockIdx.y));
+}
+// The right-hand side of Rosenbrock stage 1 and, as one more row of workgroups (the last blockIdx.y), the
+// sampled backward-error probe of the stage-0 solve (tfk_berr's one-node form): both only read what the
+// solve left, and the probe's own launch cost a step of config 3 ~10 us for 10 MB of loads.
+__global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_sweep_f_stage_rhs_mon(TfStageMonArgs a) {
+    if (blockIdx.y + 1 == gridDim.y) { tf_berr_reduce(a.b, tfk_berr_body(a.b, TF_GID, 0)); return; }
+    tfk_sweep_body<false, true, false, false, true, TF_STAGE_SEG>(a.s, TF_GID, blockIdx.y);
 }
 
 // grid (nblocks, nvar*nsys): deterministic tree inside the block, one partial per block
@@ -462,10 +471,11 @@ __global__ void __launch_bounds__(512) tfk_s_fwd(TfScalarArgs t) {
         // the stored reductions of this level-2 chunk and of level 3's one chunk: requested before the
         // walks (they do not depend on the right-hand side) and put into LDS after them, so that neither
         // the walks nor the levels wait for memory (put before the walks: 1.8 us of every workgroup)
-        __shared__ double sF2[TfCrs<TF_B2>::FSIZE], sF3[TfCrs<TF_B2>::FSIZE];
+        __shared__ double sF2[(TF_CRS_MAXLEN + 1) * 5 * TF_B2 * TF_B2], sF3[TfCrs<TF_B2>::FSIZE];
         TF_STAMP(l2, 57);
         TF_STAMP_REAL(l2, 30);
-        TfCrsStaged<TF_B2, 512> rF2, rF3;
+        TfCrsStaged<TF_B2, 512, TF_CRS_MAXLEN> rF2;
+        TfCrsStaged<TF_B2, 512, TF_CRS_TOPLEN(TF_B2)> rF3;
         tfk_crs_stage_request<TF_B2, 512>(l2, (int)blockIdx.x, tid, rF2);
         tfk_crs_stage_request<TF_B2, 512>(t.lv[2], ch.e, tid, rF3);
         // (thread 0: the inverse of the folded top block, for whichever workgroup solves level 3)

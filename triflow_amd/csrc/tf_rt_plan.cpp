@@ -122,9 +122,11 @@ tf_solver* make_solver(tf_model* model, int64_t N, int32_t nsys, int32_t periodi
         // the reduced levels that cheap the shortest such chunks win (config 2: m1 = 16 against 32:
         // 19 400 against 18 400 steps/s, 16 000 against 14 600 factorising in every step,
         // profiles/r04_ab_runs.txt)
+        // (a level that is one chunk may be TF_CRS_TOPLEN long: b = 1 keeps m1 = 16 up to N = 2e6.  m1 = 8
+        // with twice the workgroups: 20 500 against 21 000, the last workgroup arrives no earlier)
         if (s->use_cr && !dispersive_capable && b2 <= 2 && total > 600000) {
             m1 = 16;
-            while (N / m1 > 65536) m1 *= 2;
+            while (N / m1 > TF_CRS_MAXLEN * TF_CRS_TOPLEN(b2)) m1 *= 2;
         }
     }
     m1 = std::max(m1, 2 * sp.mp);
@@ -148,6 +150,8 @@ tf_solver* make_solver(tf_model* model, int64_t N, int32_t nsys, int32_t periodi
             const bool cr = !first && s->use_cr && (int64_t)n * nsys <= cr_max_nodes;
             int P = std::max(1, n / m);
             if (cr) P = (n + cr_len - 1) / cr_len;                 // chunk length <= cr_len
+            // (scalar models: what fits one chunk of the longer kind is the last level)
+            if (cr && b2 <= 2 && cr_len == cr_cap && n <= TF_CRS_TOPLEN(b2)) P = 1;
             std::unique_ptr<Level> lv(new Level());
             lv->L = make_layout(nsys, n, P, s->periodic);
             lv->B = B; lv->MP = MP; lv->cr = cr;

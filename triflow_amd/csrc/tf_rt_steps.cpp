@@ -30,6 +30,7 @@ void step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns, con
     s->sweep(Uin, true, 0, nullptr, nullptr, dt);   // J(U) and dt*F(U): right-hand side of stage 0
     const double* ks[TF_MAX_TERMS];
     double cs[TF_MAX_TERMS];
+    bool probe_due = false;
     for (int i = 0; i < ns; ++i) {
         if (i > 0) {
             // F(U + sum_j alpha_ij k_j): the stage state is formed inside the sweep.  It goes to a
@@ -37,16 +38,19 @@ void step_row(tf_solver* s, int32_t src, int32_t dst, double dt, int32_t ns, con
             // ... plus dt*(J @ sum_j gamma_ij k_j), in the same pass
             double gs[TF_MAX_TERMS];
             for (int j = 0; j < i; ++j) { ks[j] = s->K[j].p; cs[j] = alpha[i * ns + j]; gs[j] = gamma[i * ns + j]; }
-            s->stage_rhs(Uin, i, ks, cs, gs, dt, s->Wrhs.p);
+            // (i == 1: with the backward-error probe of the stage-0 solve, (I - gamma dt J) k0 = dt F(U), at one
+            // node per chunk -- every step between the synchronising checks, nobody waits for it)
+            if (i == 1 && probe_due) {
+                const TfBerrArgs probe = s->probe_args(s->F.p, s->K[0].p, nullptr);
+                s->stage_rhs(Uin, i, ks, cs, gs, dt, s->Wrhs.p, &probe);
+            } else s->stage_rhs(Uin, i, ks, cs, gs, dt, s->Wrhs.p);
         }
         // the last stage of a fixed step of one or two stages: the new state leaves with the solve
         if (i == ns - 1 && ns <= 2 && !(b_pred && want_err))
             s->request_update(U, Uin, ns == 2 ? s->K[0].p : nullptr, b[0], ns == 2 ? b[1] : 0.0, ns);
         if (i == 0) {
             s->factor_step(gamma[0] * dt, s->F.p, s->K[0].p);         // factorise + first stage
-            // the backward error of that solve, (I - gamma dt J) k0 = dt F(U), at one node per chunk: a small
-            // launch nobody waits for, every step between the synchronising checks (monitor_sampled)
-            if (ns > 1 && s->sampled_monitor_due()) s->monitor_sampled(s->F.p, s->K[0].p, nullptr);
+            probe_due = ns > 1 && s->sampled_monitor_due();
         } else s->solve(s->Wrhs.p, s->K[i].p);
     }
     for (int j = 0; j < ns; ++j) { ks[j] = s->K[j].p; cs[j] = b[j]; }

@@ -446,7 +446,8 @@ struct tf_solver {
     int* tiny_piv = nullptr;
     TfTinyArgs tiny_args(const double* rhs1, double* x1);
     bool l1_fuse_backsub = true;   // twisted form: tfk_l1_fwd2_backsub (TRIFLOW_L1_FUSE_BACKSUB=0: two launches)
-    void stage_rhs(const double* Uin, int nterms, const double* const* ks, const double* ac, const double* gc, double dt, double* y);
+    void stage_rhs(const double* Uin, int nterms, const double* const* ks, const double* ac, const double* gc, double dt, double* y,
+                   const TfBerrArgs* probe = nullptr);     // probe (one term, fused form): rides in the same launch
     // y = cF*F + cA*(J @ sum_t vc_t vx_t)
     void spmv_stage(int nterms, const double* const* vx, const double* vc, const double* Fp, double cF, double cA, double* y);
 
@@ -532,6 +533,7 @@ struct tf_solver {
     unsigned mon_phase = 0;
     bool sampled_monitor_due() const;
     void monitor_sampled(const double* rhs1, const double* x1, const double* xbase);
+    TfBerrArgs probe_args(const double* rhs1, const double* x1, const double* xbase);     // (marks the monitor as used)
     // x = (I - c J)^-1 rhs.  refine > 0: that many refinement sweeps; refine == -1
     // (default): the first solve after every factorisation measures the backward
     // error, and only a factorisation that lost accuracy (block elimination does

@@ -263,15 +263,22 @@ bool tf_solver::sampled_monitor_due() const {
     return refine < 0 && !reused && !delegated && !tiny && have_factor && !(refine == -1 && check_now);
 }
 
-void tf_solver::monitor_sampled(const double* rhs1, const double* x1, const double* xbase) {
+TfBerrArgs tf_solver::probe_args(const double* rhs1, const double* x1, const double* xbase) {
     TfBerrArgs a;
     std::memset(&a, 0, sizeof(a));
     a.L = L1; a.Jv = Jv.p; a.x = x1; a.rhs = rhs1; a.c = factor_c; a.red = red.p + 4;
     a.parsca = parsca.p; a.dx = dx.p; a.xbase = xbase;
-    // (a stride coprime with every chunk length up to 64: consecutive steps look at nodes far apart)
+    // (a stride coprime with every chunk length up to 64: consecutive steps look at nodes far apart.  Looking
+    // at a quarter of the chunks per step on very many chunks was tried for config 5: nothing, its `tfk_berr`
+    // time is the full passes of the synchronising checks, profiles/r04_ab_runs.txt)
     a.one_node = (int)((mon_phase++ * 13u) % 4096u);
-    launch(TFK_BERR, sweep_gx(), 1, spec.sweep_block, &a, sizeof(a));
     monitored = true;
+    return a;
+}
+
+void tf_solver::monitor_sampled(const double* rhs1, const double* x1, const double* xbase) {
+    TfBerrArgs a = probe_args(rhs1, x1, xbase);
+    launch(TFK_BERR, sweep_gx(), 1, spec.sweep_block, &a, sizeof(a));
 }
 
 void tf_solver::solve(const double* rhs1, double* x1) {

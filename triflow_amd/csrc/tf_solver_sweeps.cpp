@@ -165,8 +165,9 @@ TfTinyArgs tf_solver::tiny_args(const double* rhs1, double* x1) {
     return t;
 }
 
-void tf_solver::stage_rhs(const double* Uin, int nterms, const double* const* ks, const double* ac, const double* gc, double dt, double* y) {
+void tf_solver::stage_rhs(const double* Uin, int nterms, const double* const* ks, const double* ac, const double* gc, double dt, double* y, const TfBerrArgs* probe) {
     if (!fuse_stage) {
+        if (probe) launch(TFK_BERR, sweep_gx(), 1, spec.sweep_block, probe, sizeof(*probe));
         sweep(Uin, false, nterms, ks, ac, 1.0, Wstage.p);
         spmv_stage(nterms, ks, gc, Wstage.p, dt, dt, y);
         return;
@@ -179,6 +180,13 @@ void tf_solver::stage_rhs(const double* Uin, int nterms, const double* const* ks
     a.dx = dx.p; a.xcoord = xcoord.p; a.F = Wstage.p; a.Jv = Jv.p;
     a.stage_rhs = y; a.cF = dt; a.cA = dt;
     unsigned gx = sweep_gx(), gy = cdiv(L1.M, TF_STAGE_SEG);
+    if (probe && nterms == 1) {
+        TfStageMonArgs m;
+        m.s = a; m.b = *probe;
+        launch(TFK_SWEEP_F_STAGE_RHS_MON, gx, gy + 1, spec.sweep_block, &m, sizeof(m));
+        return;
+    }
+    if (probe) launch(TFK_BERR, gx, 1, spec.sweep_block, probe, sizeof(*probe));
     launch(nterms >= 2 && nterms <= 5 ? TFK_SWEEP_F_STAGE_RHS_N : TFK_SWEEP_F_STAGE_RHS, gx, gy, spec.sweep_block, &a, sizeof(a));
 }
 
