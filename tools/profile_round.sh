@@ -29,5 +29,5 @@ for k, v in res.items():
     if k.startswith("tfk_sweep"): print(k, v)
 PY
 cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv
-tail -1 $OUT/bench_trace.log > $OUT/bench_under_rocprof.json
-tail -1 $OUT/bench_trace.log | cut -c1-400
+grep '"metric"' $OUT/bench_trace.log | tail -1 > $OUT/bench_under_rocprof.json      # (rocprofv3 prints after the program's last line)
+cut -c1-400 $OUT/bench_under_rocprof.json
