@@ -212,9 +212,10 @@ int tf_diff_norm(tf_solver*, int32_t slot_a, int32_t slot_b, int32_t ord, double
  * refinement */
 int tf_backward_error(tf_solver*, double* omega, int32_t* refined);
 
-/* Rosenbrock steps measure the backward error of their factorisation's first solve inside the
- * J @ v pass of stage 1 (no launch or synchronisation of its own; halfway between two explicit
- * checks, every step with refine = -2); the worst value
+/* Between two explicit (synchronising) checks every step measures the backward error of its
+ * factorisation's first solve at one node of every level-1 chunk, a different node in every step (no
+ * synchronisation; a Rosenbrock step inside the launch of stage 1's right-hand side, a Theta / BDF-2
+ * step in a small launch of its own; with refine = -2 there are no explicit checks).  The worst value
  * since the last synchronising call is looked at there (above 1e-11: the next factorisation is
  * checked and refined; above 1e-6: RuntimeError).  This reads it without resetting / raising. */
 int tf_monitor_error(tf_solver*, double* worst);
