@@ -488,18 +488,18 @@ __device__ __forceinline__ int tf_gj_coop(double (&S)[BB], double (&INV)[BB], bo
 // 5*BB*BB doubles and a row at g*BB, so for even BB a row is 16-byte aligned and goes as
 // BB/2 x global_load_dwordx4 instead of BB x dwordx2 (half the requests of the solve kernels).
 template <int BB>
-__device__ __forceinline__ void tf_load_row(const double* p, bool on, double (&dst)[BB]) {
+__device__ __forceinline__ void tf_load_row(const double* p, double (&dst)[BB]) {
     if constexpr (BB % 2 == 0) {
         const double2* q = reinterpret_cast<const double2*>(__builtin_assume_aligned(p, 16));
 #pragma unroll
         for (int m = 0; m < BB / 2; ++m) {
             const double2 v = q[m];
-            dst[2 * m] = on ? v.x : 0.0;
-            dst[2 * m + 1] = on ? v.y : 0.0;
+            dst[2 * m] = v.x;
+            dst[2 * m + 1] = v.y;
         }
     } else {
 #pragma unroll
-        for (int m = 0; m < BB; ++m) dst[m] = on ? p[m] : 0.0;
+        for (int m = 0; m < BB; ++m) dst[m] = p[m];
     }
 }
 
@@ -569,9 +569,11 @@ __device__ __forceinline__ void tfk_cr_fwd_load(const TfCrChunk<BB>& ch, int tid
         const double* rk = io.crf0 + ((onA ? k : 1) - 1) * 5 * B2 + g * BB;
         const double* rl = io.crf0 + ((vL ? kL : 1) - 1) * 5 * B2 + 4 * B2 + g * BB;
         const double* rr = io.crf0 + ((vR ? kR : 1) - 1) * 5 * B2 + 3 * B2 + g * BB;
-        tf_load_row<BB>(rk, onA, rows.Di[r]);
-        tf_load_row<BB>(rl, vL, rows.Lb[r]);
-        tf_load_row<BB>(rr, vR, rows.Ua[r]);
+        // (a lane without the task loads node 1's row and never uses it: every use sits behind the task's
+        // own condition -- masking the 12 b values to zero was 24 b instructions per chunk)
+        tf_load_row<BB>(rk, rows.Di[r]);
+        tf_load_row<BB>(rl, rows.Lb[r]);
+        tf_load_row<BB>(rr, rows.Ua[r]);
     }
 }
 // ... and the chunk's right-hand side records, TF_CR_NYS(b) values per lane
@@ -602,6 +604,7 @@ __device__ __forceinline__ void tfk_cr_fwd_chunk(const TfLevelArgs& a, const TfC
     double (&sZ)[TfCrSolveLds<BB>::NPOS][BB] = sh.sZ;
     double* sYr = sh.sYr;
 
+    double* const zt0 = a.zt + (ch.nbase + ch.start - 1) * BB + (row_on ? g : 0);     // z of position k: zt0[k * BB]
     tf_wave_sync();                                  // (the block may still be read by the previous chunk's phases)
     TfCrFwdRows<BB> own;
     if constexpr (PRE) {
@@ -634,7 +637,7 @@ __device__ __forceinline__ void tfk_cr_fwd_chunk(const TfLevelArgs& a, const TfC
 #pragma unroll
                 for (int m = 0; m < BB; ++m) z = tf_fma(Di[r][m], sY[k][m], z);
                 sZ[k][g] = z;
-                a.zt[(ch.nbase + ch.node(k)) * BB + g] = z;
+                zt0[k * BB] = z;
                 if (KEEPZ) zkeep[r] = z;
             }
             tf_wave_sync();
@@ -648,7 +651,7 @@ __device__ __forceinline__ void tfk_cr_fwd_chunk(const TfLevelArgs& a, const TfC
                 double yl = 0.0, yu = 0.0;
 #pragma unroll
                 for (int m = 0; m < BB; ++m) {
-                    yl = tf_fma(-Lb[r][m], sZ[kL][m], yl);      // rows are zero where there is no update
+                    yl = tf_fma(-Lb[r][m], sZ[kL][m], yl);      // (used behind vL / vR only)
                     yu = tf_fma(-Ua[r][m], sZ[kR][m], yu);
                 }
                 if (vL) sY[aL][g] += yl;
@@ -723,9 +726,9 @@ __device__ __forceinline__ void tfk_cr_bwd_load(const TfLevelArgs& a, const TfCr
         const bool on = s <= mI && grp < nA && row_on;
         const int k = on ? s * (2 * grp + 1) : 1;
         const double* rec = io.crf0 + (k - 1) * 5 * B2 + g * BB;
-        tf_load_row<BB>(rec + 1 * B2, on, rows.Er[r]);
-        tf_load_row<BB>(rec + 2 * B2, on, rows.Fr[r]);
-        if (load_z) rows.zk[r] = on ? a.zt[(ch.nbase + ch.node(k)) * BB + g] : 0.0;
+        tf_load_row<BB>(rec + 1 * B2, rows.Er[r]);
+        tf_load_row<BB>(rec + 2 * B2, rows.Fr[r]);
+        if (load_z) rows.zk[r] = a.zt[(ch.nbase + ch.node(k)) * BB + (row_on ? g : 0)];
     }
 }
 
@@ -749,11 +752,12 @@ __device__ __forceinline__ void tfk_cr_bwd_run(const TfLevelArgs& a, const TfCrC
     const bool row_on = g < BB;
     const int mI = ch.mI, pe = ch.pe;
     double (&sX)[TfCrSolveLds<BB>::NPOS][BB] = sh.sY;
+    double* const x0 = a.x + (ch.nbase + ch.start - 1) * BB + (row_on ? g : 0);       // x of position k: x0[k * BB]
     tf_wave_sync();
     if (row_on && grp == 0) {
         const double xs = PREX ? xsep : io.xn_own[g];
         sX[pe][g] = xs;
-        a.x[(ch.nbase + ch.node(pe)) * BB + g] = xs;
+        x0[pe * BB] = xs;
     }
     if (row_on && grp == 1) sX[0][g] = PREX ? xsep : (io.has_xprev ? io.xn_prev[g] : 0.0);
     tf_wave_sync();
@@ -781,7 +785,7 @@ __device__ __forceinline__ void tfk_cr_bwd_run(const TfLevelArgs& a, const TfCrC
                     }
                 }
                 sX[k][g] = xk;
-                a.x[(ch.nbase + ch.node(k)) * BB + g] = xk;
+                x0[k * BB] = xk;
             }
             tf_wave_sync();
         }
