@@ -21,7 +21,10 @@
 // the compiler only has to keep them in order
 #define TF_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+// (loads stay where they are written: the compiler otherwise sinks one towards its only use)
+#define TF_KEEP_ORDER() __asm__ volatile("" ::: "memory")
 #else
+#define TF_KEEP_ORDER() do {} while (0)
 #define TF_WAVE_SYNC() do {} while (0)
 #define TF_ST_AGENT(p, v) (*(p) = (v))
 #define TF_LD_AGENT(p) (*(p))
@@ -57,12 +60,19 @@ struct TfCrChunk {
 // chunks, where the chunk walks needed 6 levels of three kernels each).
 template <int BB> struct TfCrs {
     static constexpr int MAXLEN = TF_CRS_TOPLEN(BB), NPOS = MAXLEN + 1;
-    // LDS places of the solve kernels (tfk_crs_fwd / tfk_crs_bwd): a vector [pos][b], records [pos][5][b][b].
-    // (Padding them against the bank conflicts of the power-of-two strides of the rounds changed nothing:
-    // a round is bound by the instructions one wavefront issues, profiles/r04_scalar_stamps.txt.)
+    // LDS places of the solve kernels (tfk_crs_fwd / tfk_crs_bwd): a vector [pos][b]; the stored reduction by
+    // FIELD, [5][pos][b][b] (Dinv, E, F, Ua, Lb) -- a node's five blocks then sit at one address plus constants
+    // (a round is bound by the instructions one wavefront issues, profiles/r04_scalar_stamps.txt: padding
+    // the arrays against the bank conflicts of the rounds' power-of-two strides changed nothing, fewer
+    // address instructions do).
     static constexpr int VSIZE = NPOS * BB, FSIZE = NPOS * 5 * BB * BB;
     TF_DEVICE_M static int v(int pos, int q) { return pos * BB + q; }
-    TF_DEVICE_M static int f(int pos) { return pos * 5 * BB * BB; }
+    TF_DEVICE_M static int f(int pos, int fld = 0) { return (fld * NPOS + pos) * BB * BB; }
+    // ... of entry i of a chunk's records as they are in memory ([node][5][b][b], from the chunk's first node)
+    TF_DEVICE_M static int fmem(int i) {
+        const int nd = i / (5 * BB * BB), rem = i - nd * 5 * BB * BB, fld = rem / (BB * BB);
+        return f(nd + 1, fld) + rem - fld * BB * BB;
+    }
 };
 
 // small-block helpers on rows stored as [r * BB + c] in LDS / global memory
@@ -251,10 +261,7 @@ template <int BB, int NT>
 TF_DEVICE void tfk_crs_stage(const TfLevelArgs& a, int chunk, int tid, double* sF) {
     const TfCrChunk<BB> ch(a.L, chunk);
     const double* src = a.crf + (ch.nbase + ch.start) * 5 * BB * BB;
-    for (int i = tid; i < ch.len * 5 * BB * BB; i += NT) {
-        const int nd = i / (5 * BB * BB);
-        sF[TfCrs<BB>::f(nd + 1) + i - nd * 5 * BB * BB] = src[i];
-    }
+    for (int i = tid; i < ch.len * 5 * BB * BB; i += NT) sF[TfCrs<BB>::fmem(i)] = src[i];
 }
 // ... in two parts, for a caller with work to do while the loads are in flight: request (into registers),
 // then put into LDS
@@ -273,8 +280,8 @@ TF_DEVICE void tfk_crs_stage_put(const TfLevelArgs& a, int chunk, int tid, const
     constexpr int NQ = (LEN * 5 * BB * BB + NT - 1) / NT;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int i = tid + q * NT, nd = i / (5 * BB * BB);
-        if (i < ch.len * 5 * BB * BB) sF[TfCrs<BB>::f(nd + 1) + i - nd * 5 * BB * BB] = regs.v[q];
+        const int i = tid + q * NT;
+        if (i < ch.len * 5 * BB * BB) sF[TfCrs<BB>::fmem(i)] = regs.v[q];
     }
 }
 
@@ -311,12 +318,47 @@ TF_DEVICE void tfk_crs_fwd(const TfLevelArgs& a, int chunk, int tid, double* sF_
     // and the next round's first half need one set of LDS loads and one synchronisation -- a wavefront
     // alone on its SIMD issues an instruction every ~5 cycles and waits ~130 for LDS: a round of two
     // phases took 1150 cycles (profiles/r04_scalar_stamps.txt).
-    // Phases with at most 64 tasks (all but the first two of a 256-node chunk) are run by the first
-    // wavefront ALONE, with no workgroup barrier in between.  `alone`: the other wavefronts have not been
-    // synchronised with what the first one wrote since; a barrier is due before they take part again,
-    // and at the end.
-    constexpr int WS = NT > 64 ? 64 : NT;
-    bool alone = false;
+    // Rounds with at most 64 tasks (all but the first two of a 256-node chunk) are run by the first
+    // wavefront ALONE in a loop of its own, with no workgroup barrier and none of their bookkeeping; one
+    // barrier lets the other wavefronts see the result.
+    double* const zt0 = a.zt + (ch.nbase + ch.start - 1) * BB;       // (wave-uniform: z / x of position k at [k * BB])
+    double* const x0 = a.x + (ch.nbase + ch.start - 1) * BB;
+    auto task = [&](int r, int t) {
+        const int s = 1 << r, nq = mI >> r, nB = nq >> 1;
+        const int nA1 = (2 << r) <= mI ? ((mI >> (r + 1)) + 1) >> 1 : 0;      // nodes that leave in round r + 1
+        const bool ends = t == nB;
+        const int aa = 2 * s * (t + 1);
+        const int aL = ends ? pe : aa, aU = ends ? 0 : aa;
+        const bool vL = ends ? (nq & 1) != 0 : true;
+        const bool vR = ends ? true : aa + s <= mI;
+        const int kL = vL ? (ends ? nq * s : aa - s) : 1, kR = vR ? (ends ? s : aa + s) : 1;
+        const bool next = !ends && (t & 1) == 0 && (t >> 1) < nA1;    // aa = 2 s (2 j' + 1), j' = t / 2
+        // every load of the task before the first use: one LDS latency
+        double Lb[BB][BB], Ua[BB][BB], Di[BB][BB], zl[BB], zr[BB], yl[BB], yu[BB];
+        tf_ld_blk<BB>(Lb, sF + C::f(kL, 4));
+        tf_ld_blk<BB>(Ua, sF + C::f(kR, 3));
+        tf_ld_blk<BB>(Di, sF + C::f(ends ? 1 : aa));
+#pragma unroll
+        for (int q = 0; q < BB; ++q) { zl[q] = sZ[C::v(kL, q)]; zr[q] = sZ[C::v(kR, q)]; yl[q] = sY[C::v(aL, q)]; yu[q] = sY[C::v(aU, q)]; }
+        TF_KEEP_ORDER();
+        if (vL) tf_mv_sub<BB>(yl, Lb, zl);
+        if (!ends) {
+            // (one node takes both updates, the lower neighbour's first)
+            if (vR) tf_mv_sub<BB>(yl, Ua, zr);
+#pragma unroll
+            for (int q = 0; q < BB; ++q) sY[C::v(aL, q)] = yl[q];
+            if (next) {
+                double z[BB];
+                tf_mv<BB>(z, Di, yl);
+#pragma unroll
+                for (int q = 0; q < BB; ++q) { sZ[C::v(aa, q)] = z[q]; zt0[aa * BB + q] = z[q]; }
+            }
+        } else {
+            if (vR) tf_mv_sub<BB>(yu, Ua, zr);
+#pragma unroll
+            for (int q = 0; q < BB; ++q) { if (vL) sY[C::v(aL, q)] = yl[q]; if (vR) sY[C::v(aU, q)] = yu[q]; }
+        }
+    };
     if (mI >= 1) {
         const int nA = (mI + 1) >> 1;                        // round 0's first half: the odd nodes
         for (int j = tid; j < nA; j += NT) {
@@ -327,106 +369,87 @@ TF_DEVICE void tfk_crs_fwd(const TfLevelArgs& a, int chunk, int tid, double* sF_
             for (int q = 0; q < BB; ++q) y[q] = sY[C::v(k, q)];
             tf_mv<BB>(z, Di, y);
 #pragma unroll
-            for (int q = 0; q < BB; ++q) { sZ[C::v(k, q)] = z[q]; a.zt[(ch.nbase + ch.node(k)) * BB + q] = z[q]; }
+            for (int q = 0; q < BB; ++q) { sZ[C::v(k, q)] = z[q]; zt0[k * BB + q] = z[q]; }
         }
         TF_BARRIER();
     }
-    for (int r = 0; (1 << r) <= mI; ++r) {
-        const int s = 1 << r, nq = mI >> r, nB = nq >> 1;
-        const int nA1 = (2 << r) <= mI ? ((mI >> (r + 1)) + 1) >> 1 : 0;      // nodes that leave in round r + 1
-        const bool solo = NT > 64 && nB + 1 <= 64;
-        if (!solo && alone) { TF_BARRIER(); alone = false; }
-        const int st = solo ? WS : NT;
-        if (!solo || tid < WS)
-            for (int t = tid; t <= nB; t += st) {
-                const bool ends = t == nB;
-                const int aa = 2 * s * (t + 1);
-                const int aL = ends ? pe : aa, aU = ends ? 0 : aa;
-                const bool vL = ends ? (nq & 1) != 0 : true;
-                const bool vR = ends ? true : aa + s <= mI;
-                const int kL = vL ? (ends ? nq * s : aa - s) : 1, kR = vR ? (ends ? s : aa + s) : 1;
-                const bool next = !ends && (t & 1) == 0 && (t >> 1) < nA1;    // aa = 2 s (2 j' + 1), j' = t / 2
-                // (every load of the task before the first use)
-                double Lb[BB][BB], Ua[BB][BB], Di[BB][BB], zl[BB], zr[BB], yl[BB], yu[BB];
-                tf_ld_blk<BB>(Lb, sF + C::f(kL) + 4 * B2);
-                tf_ld_blk<BB>(Ua, sF + C::f(kR) + 3 * B2);
-                tf_ld_blk<BB>(Di, sF + C::f(next ? aa : 1));
-#pragma unroll
-                for (int q = 0; q < BB; ++q) { zl[q] = sZ[C::v(kL, q)]; zr[q] = sZ[C::v(kR, q)]; yl[q] = sY[C::v(aL, q)]; yu[q] = sY[C::v(aU, q)]; }
-                if (vL) tf_mv_sub<BB>(yl, Lb, zl);
-                if (!ends) {
-                    // (one node takes both updates, the lower neighbour's first)
-                    if (vR) tf_mv_sub<BB>(yl, Ua, zr);
-#pragma unroll
-                    for (int q = 0; q < BB; ++q) sY[C::v(aL, q)] = yl[q];
-                    if (next) {
-                        double z[BB];
-                        tf_mv<BB>(z, Di, yl);
-#pragma unroll
-                        for (int q = 0; q < BB; ++q) { sZ[C::v(aa, q)] = z[q]; a.zt[(ch.nbase + ch.node(aa)) * BB + q] = z[q]; }
-                    }
-                } else {
-                    if (vR) tf_mv_sub<BB>(yu, Ua, zr);
-#pragma unroll
-                    for (int q = 0; q < BB; ++q) { if (vL) sY[C::v(aL, q)] = yl[q]; if (vR) sY[C::v(aU, q)] = yu[q]; }
-                }
+    constexpr bool WAVES = NT > 64;                          // (the host emulation: one "thread", no wavefronts)
+    int r = 0;
+    for (; (1 << r) <= mI && (!WAVES || ((mI >> r) >> 1) + 1 > 64); ++r) {
+        const int nB = (mI >> r) >> 1;
+        for (int t = tid; t <= nB; t += NT) task(r, t);
+        TF_BARRIER();
+    }
+    const int r_solo = r;                                    // the first round the first wavefront runs alone
+    if (WAVES && (1 << r) <= mI) {
+        if (tid < 64)
+            for (; (1 << r) <= mI; ++r) {
+                if (tid <= ((mI >> r) >> 1)) task(r, tid);
+                TF_WAVE_SYNC();
             }
-        if (solo) { TF_WAVE_SYNC(); alone = true; } else TF_BARRIER();
+        if (!a.fold_top) TF_BARRIER();
     }
     if (a.fold_top) {
+        // (everything up to the barrier below is the first wavefront's, in program order)
         if (tid == 0) {
             const int nsys = L.Ptot;
             double Si[BB][BB], yt[BB], x[BB];
 #pragma unroll
-            for (int r = 0; r < BB; ++r) {
-                yt[r] = sY[C::v(pe, r)] + sY[C::v(0, r)];
+            for (int q = 0; q < BB; ++q) {
+                yt[q] = sY[C::v(pe, q)] + sY[C::v(0, q)];
 #pragma unroll
-                for (int c = 0; c < BB; ++c) Si[r][c] = PRE ? top_pre[r * BB + c] : a.topAinv[(int64_t)(r * BB + c) * nsys + ch.e];
+                for (int c = 0; c < BB; ++c) Si[q][c] = PRE ? top_pre[q * BB + c] : a.topAinv[(int64_t)(q * BB + c) * nsys + ch.e];
             }
             tf_mv<BB>(x, Si, yt);
 #pragma unroll
-            for (int r = 0; r < BB; ++r) {
-                a.topx[(int64_t)ch.e * BB + r] = x[r];
-                a.x[(ch.nbase + ch.node(pe)) * BB + r] = x[r];
-                sY[C::v(pe, r)] = x[r];
-                sY[C::v(0, r)] = ch.has_prev ? x[r] : 0.0;
+            for (int q = 0; q < BB; ++q) {
+                a.topx[(int64_t)ch.e * BB + q] = x[q];
+                x0[pe * BB + q] = x[q];
+                sY[C::v(pe, q)] = x[q];
+                sY[C::v(0, q)] = ch.has_prev ? x[q] : 0.0;
             }
         }
-        if (alone) TF_WAVE_SYNC(); else TF_BARRIER();
-        int r = 0;
-        while ((2 << r) <= mI) ++r;
-        for (; r >= 0; --r) {
-            const int s = 1 << r, nA = ((mI >> r) + 1) >> 1;
-            const bool solo = NT > 64 && nA <= 64;
-            if (!solo && alone) { TF_BARRIER(); alone = false; }
-            const int st = solo ? WS : NT;
-            if (!solo || tid < WS)
-                for (int j = tid; j < nA; j += st) {
-                    const int k = s * (2 * j + 1);
-                    const int kl = k - s, kr = k + s <= mI ? k + s : pe;
-                    double E[BB][BB], F[BB][BB], xl[BB], xr[BB], xk[BB];
-                    tf_ld_blk<BB>(E, sF + C::f(k) + B2); tf_ld_blk<BB>(F, sF + C::f(k) + 2 * B2);
+        auto back = [&](int rr, int j) {
+            const int s = 1 << rr, k = s * (2 * j + 1);
+            const int kl = k - s, kr = k + s <= mI ? k + s : pe;
+            double E[BB][BB], F[BB][BB], xl[BB], xr[BB], xk[BB];
+            tf_ld_blk<BB>(E, sF + C::f(k, 1)); tf_ld_blk<BB>(F, sF + C::f(k, 2));
 #pragma unroll
-                    for (int q = 0; q < BB; ++q) { xk[q] = sZ[C::v(k, q)]; xl[q] = sY[C::v(kl, q)]; xr[q] = sY[C::v(kr, q)]; }
-                    tf_mv_sub<BB>(xk, E, xl); tf_mv_sub<BB>(xk, F, xr);
+            for (int q = 0; q < BB; ++q) { xk[q] = sZ[C::v(k, q)]; xl[q] = sY[C::v(kl, q)]; xr[q] = sY[C::v(kr, q)]; }
+            tf_mv_sub<BB>(xk, E, xl); tf_mv_sub<BB>(xk, F, xr);
 #pragma unroll
-                    for (int q = 0; q < BB; ++q) { sY[C::v(k, q)] = xk[q]; a.x[(ch.nbase + ch.node(k)) * BB + q] = xk[q]; }
+            for (int q = 0; q < BB; ++q) { sY[C::v(k, q)] = xk[q]; x0[k * BB + q] = xk[q]; }
+        };
+        int rb = 0;
+        while ((2 << rb) <= mI) ++rb;                        // the last forward round is the first one backwards
+        if (WAVES && rb >= r_solo && mI >= 1) {
+            // the rounds the first wavefront ran alone forwards, alone backwards too
+            if (tid < 64) {
+                TF_WAVE_SYNC();
+                for (; rb >= r_solo; --rb) {
+                    if (tid < (((mI >> rb) + 1) >> 1)) back(rb, tid);
+                    TF_WAVE_SYNC();
                 }
-            if (solo) { TF_WAVE_SYNC(); alone = true; } else TF_BARRIER();
+            } else rb = r_solo - 1;
+        }
+        TF_BARRIER();
+        for (; rb >= 0 && mI >= 1; --rb) {
+            const int nA = ((mI >> rb) + 1) >> 1;
+            for (int j = tid; j < nA; j += NT) back(rb, j);
+            TF_BARRIER();
         }
     } else {
         // (the first wavefront's threads: what they read was written by it, or before a barrier)
         for (int side = tid; side < 2; side += NT) {
             const int nn = side == 0 ? ch.p : ch.pprev;
             double* rr = a.rhsnext + ((int64_t)ch.e * a.Lnext.N + nn) * 2 * BB;
-            for (int r = 0; r < BB; ++r) {
-                double* dst = side == 0 ? rr + r : rr + BB + r;
-                const double v = side == 0 ? sY[C::v(pe, r)] : sY[C::v(0, r)];
+            for (int q = 0; q < BB; ++q) {
+                double* dst = side == 0 ? rr + q : rr + BB + q;
+                const double v = side == 0 ? sY[C::v(pe, q)] : sY[C::v(0, q)];
                 if (AGENT_OUT) TF_ST_AGENT(dst, v); else *dst = v;
             }
         }
     }
-    if (alone) TF_BARRIER();
 }
 
 // store_prev: the solution of the separator above (a node of the previous chunk, known from the next
@@ -443,7 +466,7 @@ TF_DEVICE void tfk_crs_bwd(const TfLevelArgs& a, int chunk, int tid, bool store_
     TF_LDS double sX[C::VSIZE], sZ[C::VSIZE];
     {
         const double* src = a.crf + (ch.nbase + ch.start) * 5 * B2;
-        for (int i = tid; i < len * 5 * B2; i += NT) { const int nd = i / (5 * B2); sF[C::f(nd + 1) + i - nd * 5 * B2] = src[i]; }
+        for (int i = tid; i < len * 5 * B2; i += NT) sF[C::fmem(i)] = src[i];
         const double* zs = a.zt + (ch.nbase + ch.start) * BB;
         for (int i = tid; i < len * BB; i += NT) sZ[BB + i] = zs[i];
     }
@@ -455,29 +478,39 @@ TF_DEVICE void tfk_crs_bwd(const TfLevelArgs& a, int chunk, int tid, bool store_
         if (store_prev && ch.has_prev) a.x[(ch.nbase + ch.gprev) * BB + r] = sX[C::v(0, r)];
     }
     TF_BARRIER();
-    // (rounds of at most 64 tasks by the first wavefront alone: see tfk_crs_fwd)
-    constexpr int WS = NT > 64 ? 64 : NT;
-    bool alone = false;
-    int r = 0;
-    while ((2 << r) <= mI) ++r;
-    for (; r >= 0; --r) {
-        const int s = 1 << r, nA = ((mI >> r) + 1) >> 1;
-        const bool solo = NT > 64 && nA <= 64;
-        if (!solo && alone) { TF_BARRIER(); alone = false; }
-        const int st = solo ? WS : NT;
-        if (!solo || tid < WS)
-            for (int j = tid; j < nA; j += st) {
-                const int k = s * (2 * j + 1);
-                const int kl = k - s, kr = k + s <= mI ? k + s : pe;
-                double E[BB][BB], F[BB][BB], xl[BB], xr[BB], xk[BB];
-                tf_ld_blk<BB>(E, sF + C::f(k) + B2); tf_ld_blk<BB>(F, sF + C::f(k) + 2 * B2);
+    double* const x0 = a.x + (ch.nbase + ch.start - 1) * BB;
+    auto back = [&](int rr, int j) {
+        const int s = 1 << rr, k = s * (2 * j + 1);
+        const int kl = k - s, kr = k + s <= mI ? k + s : pe;
+        double E[BB][BB], F[BB][BB], xl[BB], xr[BB], xk[BB];
+        tf_ld_blk<BB>(E, sF + C::f(k, 1)); tf_ld_blk<BB>(F, sF + C::f(k, 2));
 #pragma unroll
-                for (int q = 0; q < BB; ++q) { xk[q] = sZ[C::v(k, q)]; xl[q] = sX[C::v(kl, q)]; xr[q] = sX[C::v(kr, q)]; }
-                tf_mv_sub<BB>(xk, E, xl); tf_mv_sub<BB>(xk, F, xr);
+        for (int q = 0; q < BB; ++q) { xk[q] = sZ[C::v(k, q)]; xl[q] = sX[C::v(kl, q)]; xr[q] = sX[C::v(kr, q)]; }
+        tf_mv_sub<BB>(xk, E, xl); tf_mv_sub<BB>(xk, F, xr);
 #pragma unroll
-                for (int q = 0; q < BB; ++q) { sX[C::v(k, q)] = xk[q]; a.x[(ch.nbase + ch.node(k)) * BB + q] = xk[q]; }
-            }
-        if (solo) { TF_WAVE_SYNC(); alone = true; } else TF_BARRIER();
+        for (int q = 0; q < BB; ++q) { sX[C::v(k, q)] = xk[q]; x0[k * BB + q] = xk[q]; }
+    };
+    // (rounds of at most 64 tasks by the first wavefront alone, in a loop of their own: see tfk_crs_fwd)
+    constexpr bool WAVES = NT > 64;
+    int rb = 0;
+    while ((2 << rb) <= mI) ++rb;
+    if (mI < 1) rb = -1;
+    if (WAVES) {
+        int r_many = -1;                                     // the highest round with more than 64 tasks
+        for (int q = 0; q <= rb; ++q) if ((((mI >> q) + 1) >> 1) > 64) r_many = q;
+        if (rb > r_many) {
+            if (tid < 64)
+                for (; rb > r_many; --rb) {
+                    if (tid < (((mI >> rb) + 1) >> 1)) back(rb, tid);
+                    TF_WAVE_SYNC();
+                }
+            else rb = r_many;
+            TF_BARRIER();
+        }
     }
-    if (alone) TF_BARRIER();
+    for (; rb >= 0; --rb) {
+        const int nA = ((mI >> rb) + 1) >> 1;
+        for (int j = tid; j < nA; j += NT) back(rb, j);
+        TF_BARRIER();
+    }
 }
