@@ -845,8 +845,9 @@ __device__ __forceinline__ void tfk_cr_tail_coop(const TfTailArgs& t) {
         const double* src = lb.crf + chb.nbase * 5 * B2;              // (one chunk: it starts at node 0 of the system)
 #pragma unroll
         for (int q = 0; q < NTOP; ++q) {
-            const int i = (int)threadIdx.x + 64 * NW * q;
-            topv[q] = i < P * 5 * B2 ? src[i] : 0.0;
+            // (no branch around a request: beyond the level's records the last one is read again and not used)
+            const int i = (int)threadIdx.x + 64 * NW * q, lim = P * 5 * B2 - 1;
+            topv[q] = src[i < lim ? i : lim];
         }
     }
     TfCrIo<BB> io(la, ch);
@@ -859,7 +860,8 @@ __device__ __forceinline__ void tfk_cr_tail_coop(const TfTailArgs& t) {
     for (int q = 0; q < NEF; ++q) {
         const int i = lane + 64 * q;
         const int nd = i / (2 * B2), o = i - nd * 2 * B2;
-        ef[q] = (mine && i < ch.mI * 2 * B2) ? io.crf0[nd * 5 * B2 + B2 + o] : 0.0;
+        const int ndc = nd < ch.mI ? nd : (ch.mI > 0 ? ch.mI - 1 : 0);            // (clamped, not branched around)
+        ef[q] = io.crf0[ndc * 5 * B2 + B2 + o];
     }
     TfCrBwdRows<BB> rows;
 #pragma unroll
