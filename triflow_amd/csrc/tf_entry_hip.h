@@ -77,7 +77,9 @@ __global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_sweep_f_stage(TfSweepArgs 
     tfk_sweep_body<false, true>(a, TF_GID, blockIdx.y);
 }
 __global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_sweep_f_stage_rhs(TfSweepArgs a) {
-    tfk_sweep_body<false, true, false, false, true, TF_STAGE_SEG>(a, TF_GID, blockIdx.y);
+    // (one stage vector -- stage 1 of every scheme -- without the run-time loop over them)
+    if (a.nterms == 1) tfk_sweep_body<false, true, false, false, true, TF_STAGE_SEG, 1>(a, TF_GID, blockIdx.y);
+    else tfk_sweep_body<false, true, false, false, true, TF_STAGE_SEG>(a, TF_GID, blockIdx.y);
 }
 // ... for the later stages of the 3-, 4- and 6-stage schemes: the number of stage vectors as a
 // compile-time constant (tfk_sweep_body NTERMS).  A kernel of its own: the five-term path takes
@@ -160,7 +162,7 @@ __global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_berr(TfBerrArgs a) {
 // solve left, and the probe's own launch cost a step of config 3 ~10 us for 10 MB of loads.
 __global__ void __launch_bounds__(TF_SWEEP_BLOCK) tfk_sweep_f_stage_rhs_mon(TfStageMonArgs a) {
     if (blockIdx.y + 1 == gridDim.y) { tf_berr_reduce(a.b, tfk_berr_body(a.b, TF_GID, 0)); return; }
-    tfk_sweep_body<false, true, false, false, true, TF_STAGE_SEG>(a.s, TF_GID, blockIdx.y);
+    tfk_sweep_body<false, true, false, false, true, TF_STAGE_SEG, 1>(a.s, TF_GID, blockIdx.y);      // (the host launches it for one term)
 }
 
 // grid (nblocks, nvar*nsys): deterministic tree inside the block, one partial per block
